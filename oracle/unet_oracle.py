@@ -1,0 +1,442 @@
+"""TEST INFRASTRUCTURE — CPU restatement of the reference's U-Net training hot path.
+
+This file is the *checker*: only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py may import it.  The shipped package never does.
+
+Every function restates one piece of the reference (paths relative to the
+reference checkout) with explicit formulas on torch-CPU / numpy tensors:
+
+  conv_bn_relu / double_conv   model/utils/modules.py:78-99
+  unet_forward                 model/unet.py:46-85
+  maxpool2x2                   model/unet.py:19   (nn.MaxPool2d(2, 2))
+  upsample2x_bilinear          model/unet.py:20   (nn.Upsample(2,'bilinear',align_corners=True))
+  dice_loss                    utils/loss_fn.py:63-88
+  ce_map                       utils/loss_fn.py:199-203
+  confusion_counts / metrics_update   utils/metrics.py:24-152
+  train_step                   utils/train_and_eval.py:63-121 (one batch)
+  slide_*                      utils/slide_predict.py:15-117
+
+Parity pinning: the reference ships no tests or golden vectors, so this
+restatement is pinned by outputs of the reference itself, generated in the build
+container by tests/golden/make_golden.py and committed under tests/golden/
+(checked in tests/test_oracle_golden.py).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5          # nn.BatchNorm2d default, modules.py:88,93
+BN_MOMENTUM = 0.1      # nn.BatchNorm2d default
+
+
+# ----------------------------------------------------------------------------
+# model pieces
+# ----------------------------------------------------------------------------
+def conv3x3(x, w, b):
+    """nn.Conv2d(kernel_size=3, padding=1) — modules.py:87,92."""
+    return F.conv2d(x, w, b, stride=1, padding=1)
+
+
+def batchnorm_train(z, gamma, beta, eps=BN_EPS):
+    """Training-mode BatchNorm2d: batch mean / biased variance over (N,H,W).
+    Returns (y, mean, biased_var)."""
+    mean = z.mean(dim=(0, 2, 3))
+    var = z.var(dim=(0, 2, 3), unbiased=False)
+    rstd = torch.rsqrt(var + eps)
+    y = (z - mean[None, :, None, None]) * (rstd * gamma)[None, :, None, None] + beta[None, :, None, None]
+    return y, mean, var
+
+
+def batchnorm_eval(z, gamma, beta, running_mean, running_var, eps=BN_EPS):
+    rstd = torch.rsqrt(running_var + eps)
+    return (z - running_mean[None, :, None, None]) * (rstd * gamma)[None, :, None, None] + beta[None, :, None, None]
+
+
+def update_running_stats(state, prefix, mean, var, count, momentum=BN_MOMENTUM):
+    """running = (1-m)*running + m*batch; running_var uses the UNBIASED batch variance."""
+    with torch.no_grad():
+        unbiased = var * (count / max(count - 1, 1))
+        state[prefix + ".running_mean"].mul_(1 - momentum).add_(momentum * mean.detach())
+        state[prefix + ".running_var"].mul_(1 - momentum).add_(momentum * unbiased.detach())
+        state[prefix + ".num_batches_tracked"] += 1
+
+
+def conv_bn_relu(x, state, prefix, training=True, update_stats=True):
+    """One `cbr` Sequential(conv, bn, relu) — modules.py:86-94.  `prefix` is e.g.
+    'encoder1.cbr1'; keys follow the reference state_dict ('.0.weight', '.1.running_mean', ...)."""
+    z = conv3x3(x, state[prefix + ".0.weight"], state[prefix + ".0.bias"])
+    g, b = state[prefix + ".1.weight"], state[prefix + ".1.bias"]
+    if training:
+        y, mean, var = batchnorm_train(z, g, b)
+        if update_stats:
+            count = z.shape[0] * z.shape[2] * z.shape[3]
+            update_running_stats(state, prefix + ".1", mean, var, count)
+    else:
+        y = batchnorm_eval(z, g, b, state[prefix + ".1.running_mean"], state[prefix + ".1.running_var"])
+    return torch.relu(y)
+
+
+def double_conv(x, state, prefix, training=True, update_stats=True):
+    """DoubleConv.forward — modules.py:97-99."""
+    x = conv_bn_relu(x, state, prefix + ".cbr1", training, update_stats)
+    return conv_bn_relu(x, state, prefix + ".cbr2", training, update_stats)
+
+
+def maxpool2x2(x):
+    """nn.MaxPool2d(2,2): window max; backward routes to the first maximum in
+    row-major window order (torch CPU semantics, strict '>' scan)."""
+    return F.max_pool2d(x, kernel_size=2, stride=2)
+
+
+def upsample2x_bilinear(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True), restated:
+    src = dst*(in-1)/(out-1); i0=floor(src); i1=min(i0+1,in-1); l1=src-i0; l0=1-l1;
+    out = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)."""
+    B, C, H, W = x.shape
+    Ho, Wo = 2 * H, 2 * W
+
+    def taps(n_in, n_out):
+        scale = np.float32((n_in - 1) / (n_out - 1)) if n_out > 1 else np.float32(0.0)
+        src = (np.arange(n_out, dtype=np.float32) * scale).astype(np.float32)
+        i0 = np.minimum(src.astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        l0 = (np.float32(1.0) - l1).astype(np.float32)
+        return (torch.from_numpy(i0), torch.from_numpy(i1),
+                torch.from_numpy(l0).to(x.dtype), torch.from_numpy(l1).to(x.dtype))
+
+    y0, y1, hy0, hy1 = taps(H, Ho)
+    x0, x1, wx0, wx1 = taps(W, Wo)
+    r0 = x.index_select(2, y0)
+    r1 = x.index_select(2, y1)
+    top = r0.index_select(3, x0) * wx0 + r0.index_select(3, x1) * wx1
+    bot = r1.index_select(3, x0) * wx0 + r1.index_select(3, x1) * wx1
+    return top * hy0[:, None] + bot * hy1[:, None]
+
+
+UNET_BLOCKS = ("encoder1", "encoder2", "encoder3", "encoder4", "center_conv",
+               "decoder1", "decoder2", "decoder3", "decoder4")
+
+
+def unet_channels(in_channels, base=32):
+    """(Cin, Cmid, Cout) per DoubleConv — unet.py:22-39 with modules.py:81-82."""
+    b = base
+    return OrderedDict([
+        ("encoder1", (in_channels, b // 4, b)),
+        ("encoder2", (b, b * 2 // 4, b * 2)),
+        ("encoder3", (b * 2, b * 4 // 4, b * 4)),
+        ("encoder4", (b * 4, b * 8 // 4, b * 8)),
+        ("center_conv", (b * 8, b * 16, b * 8)),
+        ("decoder1", (b * 16, b * 4 // 4, b * 4)),
+        ("decoder2", (b * 8, b * 2 // 4, b * 2)),
+        ("decoder3", (b * 4, b // 4, b)),
+        ("decoder4", (b * 2, b // 4, b)),
+    ])
+
+
+def make_state(in_channels, n_classes, base=32, seed=1, dtype=torch.float32):
+    """Deterministic (hash-generated) parameters with the reference's 128 state_dict
+    keys.  Conv weights are kaiming-like scaled (fan_out / relu, model_initial.py:11);
+    biases, BN gamma/beta get small non-trivial values so every gradient is exercised."""
+    from .datagen import hash_normalish, hash_uniform
+    st = OrderedDict()
+    k = 0
+    for name, (ci, cm, co) in unet_channels(in_channels, base).items():
+        for j, (a, b_) in enumerate(((ci, cm), (cm, co)), start=1):
+            p = f"{name}.cbr{j}"
+            std = math.sqrt(2.0 / (b_ * 9))
+            st[p + ".0.weight"] = torch.from_numpy(hash_normalish((b_, a, 3, 3), seed * 1000 + k, std)).to(dtype); k += 1
+            st[p + ".0.bias"] = torch.from_numpy(hash_uniform((b_,), seed * 1000 + k, -0.1, 0.1)).to(dtype); k += 1
+            st[p + ".1.weight"] = torch.from_numpy(hash_uniform((b_,), seed * 1000 + k, 0.5, 1.5)).to(dtype); k += 1
+            st[p + ".1.bias"] = torch.from_numpy(hash_uniform((b_,), seed * 1000 + k, -0.2, 0.2)).to(dtype); k += 1
+            st[p + ".1.running_mean"] = torch.zeros(b_, dtype=dtype)
+            st[p + ".1.running_var"] = torch.ones(b_, dtype=dtype)
+            st[p + ".1.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    std = math.sqrt(2.0 / n_classes)
+    st["out_conv.weight"] = torch.from_numpy(hash_normalish((n_classes, base, 1, 1), seed * 1000 + k, std)).to(dtype); k += 1
+    st["out_conv.bias"] = torch.from_numpy(hash_uniform((n_classes,), seed * 1000 + k, -0.1, 0.1)).to(dtype)
+    return st
+
+
+PARAM_SUFFIXES = (".0.weight", ".0.bias", ".1.weight", ".1.bias")
+
+
+def param_keys(state):
+    return [k for k in state if k.endswith(PARAM_SUFFIXES) or k.startswith("out_conv.")]
+
+
+def unet_forward(x, state, training=True, update_stats=True):
+    """UNet.forward with every Dropout2d at p=0 — unet.py:46-85."""
+    dc = lambda t, name: double_conv(t, state, name, training, update_stats)
+    x1 = dc(x, "encoder1")
+    x2 = dc(maxpool2x2(x1), "encoder2")
+    x3 = dc(maxpool2x2(x2), "encoder3")
+    x4 = dc(maxpool2x2(x3), "encoder4")
+    x5 = maxpool2x2(x4)
+    y = dc(x5, "center_conv")
+    y = dc(torch.cat([upsample2x_bilinear(y), x4], dim=1), "decoder1")
+    y = dc(torch.cat([upsample2x_bilinear(y), x3], dim=1), "decoder2")
+    y = dc(torch.cat([upsample2x_bilinear(y), x2], dim=1), "decoder3")
+    y = dc(torch.cat([upsample2x_bilinear(y), x1], dim=1), "decoder4")
+    return F.conv2d(y, state["out_conv.weight"], state["out_conv.bias"])   # unet.py:44,84
+
+
+# ----------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------
+def dice_sums(logits, target):
+    """The three pooled sums of loss_fn.py:79-80 for the foreground classes:
+    I_c = sum p_c t_c, P_c = sum p_c, T_c = sum t_c over (B,H,W)."""
+    C = logits.shape[1]
+    p = torch.softmax(logits, dim=1)
+    t = F.one_hot(target.to(torch.int64), num_classes=C).permute(0, 3, 1, 2).to(p.dtype)
+    p, t = p[:, 1:], t[:, 1:]
+    return (p * t).sum(dim=(0, 2, 3)), p.sum(dim=(0, 2, 3)), t.sum(dim=(0, 2, 3))
+
+
+def dice_loss(logits, target, class_names, smooth=1e-5):
+    """diceloss.__call__ — loss_fn.py:63-88.  total = sum(fg losses) / C (C includes
+    background); 'total_loss' is the LAST key."""
+    C = logits.shape[1]
+    inter, psum, tsum = dice_sums(logits, target)
+    loss = 1 - (2 * inter) / (psum + tsum + smooth)
+    out = OrderedDict((name, loss[i]) for i, name in enumerate(class_names))
+    out["total_loss"] = loss.sum() / C
+    return out
+
+
+def ce_map(logits, target, label_smoothing=1e-7):
+    """nn.CrossEntropyLoss(label_smoothing=1e-7, reduction='none', ignore_index=0)
+    — loss_fn.py:199-203.  Per pixel: (1-ls)*(-logp[t]) + ls*mean_c(-logp[c]);
+    zero where target == 0."""
+    logp = torch.log_softmax(logits, dim=1)
+    nll = -logp.gather(1, target[:, None].to(torch.int64)).squeeze(1)
+    smooth = -logp.mean(dim=1)
+    out = (1 - label_smoothing) * nll + label_smoothing * smooth
+    return torch.where(target == 0, torch.zeros_like(out), out)
+
+
+# ----------------------------------------------------------------------------
+# metrics
+# ----------------------------------------------------------------------------
+def argmax_first(logits_np):
+    """torch.argmax over the class axis: first maximal index; NaN counts as maximal."""
+    x = np.asarray(logits_np)
+    B, C = x.shape[0], x.shape[1]
+    best = x[:, 0].copy()
+    idx = np.zeros(best.shape, dtype=np.int64)
+    for c in range(1, C):
+        v = x[:, c]
+        take = (v > best) | (np.isnan(v) & ~np.isnan(best))
+        best = np.where(take, v, best)
+        idx = np.where(take, c, idx)
+    return idx
+
+
+def confusion_counts(logits, target):
+    """Per-sample confusion matrix cm[b, t, p] (int64): pixels of sample b with
+    target class t and predicted class p = argmax(logits).  Every TP/FN/FP/TN of
+    metrics.py:31-34 is a sum of entries of this matrix."""
+    x = logits.detach().to(torch.float32).cpu().numpy()
+    t = target.detach().cpu().numpy().astype(np.int64)
+    B, C = x.shape[0], x.shape[1]
+    pred = argmax_first(x)
+    if t.min() < 0 or t.max() >= C:
+        raise RuntimeError("Class values must be smaller than num_classes.")
+    cm = np.zeros((B, C, C), dtype=np.int64)
+    for b in range(B):
+        flat = t[b].reshape(-1) * C + pred[b].reshape(-1)
+        cm[b] = np.bincount(flat, minlength=C * C).reshape(C, C)
+    return cm
+
+
+def _counts_to_onehot_terms(cm, K):
+    """TP, FN, FP, TN as int64 [B, K] for a K-wide one-hot (K may exceed C: the extra
+    classes are empty, exactly like F.one_hot(..., num_classes=9) on 4-class data)."""
+    B, C, _ = cm.shape
+    if C > K:
+        raise RuntimeError("Class values must be smaller than num_classes.")
+    hw = cm[0].sum()
+    tp = np.zeros((B, K), dtype=np.int64)
+    fn = np.zeros((B, K), dtype=np.int64)
+    fp = np.zeros((B, K), dtype=np.int64)
+    d = np.einsum("bcc->bc", cm)
+    tp[:, :C] = d
+    fn[:, :C] = cm.sum(axis=2) - d
+    fp[:, :C] = cm.sum(axis=1) - d
+    tn = hw - tp - fn - fp
+    return tp, fn, fp, tn
+
+
+def metrics_from_counts(cm, n_names, smooth=1e-5):
+    """Metrics.update post-math (metrics.py:38-152) from the integer counts, with the
+    reference's dtypes: int64 counts -> float32 ratios (torch default dtype) ->
+    Python floats -> float64 ndarray (6, n+1), rows
+    [recall, precision, dice, f1, mIoU, accuracy]; nan_to_num at the end.
+    The recall/precision one-hots are 9 wide regardless of n (metrics.py:45-46,59-60)."""
+    n = n_names
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    # recall / precision: K = 9, per-sample ratio then batch mean
+    tp, fn, fp, _ = map(T, _counts_to_onehot_terms(cm, 9))
+    recall = (tp / (tp + fn + smooth)).mean(dim=0)
+    recalls = [recall[i + 1].item() for i in range(n)] + [recall[1:].mean().item()]
+    precision = (tp / (tp + fp + smooth)).mean(dim=0)
+    precisions = [precision[i + 1].item() for i in range(n)] + [precision[1:].mean().item()]
+    f1s = [2 * (recalls[i] * precisions[i]) / (recalls[i] + precisions[i] + smooth) for i in range(n + 1)]
+    # dice / mIoU: K = n+1, float32 sums of 0/1 pooled over the batch
+    if cm.shape[1] > n + 1:
+        raise RuntimeError("Class values must be smaller than num_classes.")
+    K = n + 1
+    tpk, fnk, fpk, tnk = _counts_to_onehot_terms(cm, K)
+    inter = T(tpk.sum(axis=0)).to(torch.float32)
+    psum = T((tpk + fpk).sum(axis=0)).to(torch.float32)
+    tsum = T((tpk + fnk).sum(axis=0)).to(torch.float32)
+    union = psum + tsum
+    dice = (2 * inter) / (union + smooth)
+    dices = [dice[i + 1].item() for i in range(n)] + [dice[1:].mean().item()]
+    union_i = psum + tsum - inter
+    iou = inter / (union_i + smooth)
+    mious = [iou[i + 1].item() for i in range(n)] + [iou[1:].mean().item()]
+    # accuracy: K = n+1, per-sample then batch mean
+    tpa, fna, fpa, tna = map(T, (tpk, fnk, fpk, tnk))
+    acc = ((tpa + tna) / (tpa + tna + fna + fpa + smooth)).mean(dim=0)
+    accs = [acc[i + 1].item() for i in range(n)] + [acc[1:].mean().item()]
+    m = np.stack([recalls, precisions, dices, f1s, mious, accs], axis=0)
+    return np.nan_to_num(m)
+
+
+def metrics_update(logits, target, class_names, smooth=1e-5):
+    return metrics_from_counts(confusion_counts(logits, target), len(class_names), smooth)
+
+
+# ----------------------------------------------------------------------------
+# one training step (the CPU baseline's unit of work)
+# ----------------------------------------------------------------------------
+def clip_grad_norm(grads, max_norm=1.0, eps=1e-6):
+    """torch.nn.utils.clip_grad_norm_ (train_and_eval.py:115): global L2 norm,
+    coef = clamp(max_norm/(norm+1e-6), max=1), grads *= coef.  Returns the norm."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+    coef = torch.clamp(max_norm / (total + eps), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr=8e-4, betas=(0.95, 0.999),
+               eps=1e-8, weight_decay=1e-4):
+    """torch.optim.AdamW single-tensor update (train.py:221-226 defaults)."""
+    b1, b2 = betas
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    with torch.no_grad():
+        for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+            p.mul_(1 - lr * weight_decay)
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+            p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+class TrainState:
+    """Parameters + AdamW moments for train_step."""
+
+    def __init__(self, state):
+        self.state = state
+        self.keys = param_keys(state)
+        for k in self.keys:
+            state[k].requires_grad_(True)
+        self.m = [torch.zeros_like(state[k]) for k in self.keys]
+        self.v = [torch.zeros_like(state[k]) for k in self.keys]
+        self.step = 0
+
+
+def train_step(ts, images, masks, class_names, lr=8e-4, timers=None):
+    """One batch of train_one_epoch (train_and_eval.py:63-121) on the fp32 CPU path
+    (autocast and GradScaler disable themselves without CUDA): forward, Dice loss,
+    metrics, backward, clip_grad_norm_(1.0), AdamW.  Returns (loss dict values as
+    floats, metrics matrix, logits)."""
+    import time
+    tick = time.perf_counter
+    st = ts.state
+    params = [st[k] for k in ts.keys]
+    for p in params:
+        p.grad = None
+    t0 = tick()
+    logits = unet_forward(images, st, training=True)
+    t1 = tick()
+    ld = dice_loss(logits, masks, class_names)
+    t2 = tick()
+    met = metrics_update(logits, masks, class_names)
+    t3 = tick()
+    ld["total_loss"].backward()
+    t4 = tick()
+    grads = [p.grad for p in params]
+    clip_grad_norm(grads, 1.0)
+    t5 = tick()
+    ts.step += 1
+    adamw_step(params, grads, ts.m, ts.v, ts.step, lr=lr)
+    t6 = tick()
+    if timers is not None:
+        for k, v in zip(("fwd", "loss", "metrics", "bwd", "clip", "adamw"),
+                        (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+            timers[k] = timers.get(k, 0.0) + v
+    return [float(v) for v in ld.values()], met, logits.detach()
+
+
+# ----------------------------------------------------------------------------
+# sliding-window prediction
+# ----------------------------------------------------------------------------
+def slide_pad(image, window, stride):
+    """_pad_image — slide_predict.py:15-29 (reflect pad on bottom/right)."""
+    h, w = image.shape[:2]
+    pad_h = (window - (h % stride)) % window
+    pad_w = (window - (w % stride)) % window
+    if pad_h > 0 or pad_w > 0:
+        image = np.pad(image, ((0, pad_h), (0, pad_w), (0, 0)), "reflect")
+    return image, (pad_h, pad_w)
+
+
+def slide_positions(h, w, window, stride):
+    """_split_image — slide_predict.py:31-58: (num+1)^2 windows, the last row/col
+    clamped to the border (which duplicates the previous one when sizes divide)."""
+    pos = []
+    num_h = (h - window) // stride + 1
+    num_w = (w - window) // stride + 1
+    for i in range(num_h + 1):
+        for j in range(num_w + 1):
+            y0, x0 = i * stride, j * stride
+            y1, x1 = y0 + window, x0 + window
+            if y1 > h:
+                y1, y0 = h, h - window
+            if x1 > w:
+                x1, x0 = w, w - window
+            pos.append((y0, y1, x0, x1))
+    return pos
+
+
+def slide_gaussian(window):
+    """The per-tile weight of slide_predict.py:95-100 (float64):
+    d = sqrt((i-w//2)^2 + (j-w//2)^2); weight = exp(-d^2 / (2*(w/4)^2))."""
+    sigma = window / 4
+    i = np.arange(window, dtype=np.float64) - window // 2
+    d = (i[:, None] ** 2 + i[None, :] ** 2) ** 0.5
+    return np.exp(-d ** 2 / (2 * sigma ** 2))
+
+
+def slide_blend(class_maps, positions, padded_hw, orig_hw, window):
+    """slide_predict.py:74-112: float32 accumulators updated tile by tile IN ORDER
+    (each += rounds float64 -> float32), divide where weight != 0, round, uint8."""
+    ph, pw = padded_hw
+    output = np.zeros((ph, pw), dtype=np.float32)
+    weight = np.zeros((ph, pw), dtype=np.float32)
+    g = slide_gaussian(window)
+    for cm, (y0, y1, x0, x1) in zip(class_maps, positions):
+        output[y0:y1, x0:x1] += cm * g
+        weight[y0:y1, x0:x1] += g
+    oh, ow = orig_hw
+    fo, fw = output[:oh, :ow], weight[:oh, :ow]
+    fo = np.divide(fo, fw, where=fw != 0)
+    return np.round(fo).astype(np.uint8)

@@ -1,0 +1,218 @@
+"""CPU suite: the oracle (oracle/unet_oracle.py) against the golden vectors that
+tests/golden/make_golden.py produced by running the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from oracle import datagen as dg
+from oracle import unet_oracle as orc
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name,c", [("dc_a", dict(B=2, cin=3, mid=8, cout=8, hw=16, seed=11)),
+                                    ("dc_b", dict(B=2, cin=16, mid=4, cout=16, hw=8, seed=12))])
+def test_double_conv(golden, name, c):
+    g = golden("double_conv")
+    st = mg.orc_double_conv_state(c["cin"], c["mid"], c["cout"], c["seed"])
+    pk = [k for k in st if k.endswith(orc.PARAM_SUFFIXES)]
+    for k in pk:
+        st[k].requires_grad_(True)
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).requires_grad_(True)
+    gy = T(dg.hash_normalish((c["B"], c["cout"], c["hw"], c["hw"]), c["seed"] + 200))
+    y = orc.double_conv(x, st, "blk", training=True)
+    y.backward(gy)
+    close(y.detach(), g[f"{name}.train_y"], 1e-4, 1e-5)
+    close(x.grad, g[f"{name}.dx"], 1e-4, 1e-5)
+    for k in pk:
+        # the conv-bias gradient is analytically zero under train-mode BN: only round-off remains
+        atol = 1e-4 if k.endswith(".0.bias") else 2e-5
+        close(st[k].grad, g[f"{name}.grad.{k[4:]}"], 2e-4, atol)
+    for k in st:
+        if "running" in k or "num_batches" in k:
+            close(st[k].detach(), g[f"{name}.buf.{k[4:]}"], 1e-5, 1e-6)
+    with torch.no_grad():
+        ye = orc.double_conv(x, st, "blk", training=False)
+    close(ye, g[f"{name}.eval_y"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("name,c", [("unet_a", dict(B=2, cin=1, ncls=4, hw=32, seed=21)),
+                                    ("unet_b", dict(B=2, cin=3, ncls=4, hw=64, seed=22)),
+                                    ("unet_c", dict(B=1, cin=1, ncls=9, hw=32, seed=23))])
+def test_unet(golden, name, c):
+    g = golden("unet")
+    # float64 oracle: the reference's CPU BatchNorm accumulates in double, and the
+    # weight gradients of a BN network cancel heavily, so a float32 restatement is
+    # noisier (up to 3e-2 on small gradient tensors) than the reference it checks.
+    st = orc.make_state(c["cin"], c["ncls"], base=8, seed=c["seed"], dtype=torch.float64)
+    assert len(st) == 128
+    keys = orc.param_keys(st)
+    assert len(keys) == 74
+    for k in keys:
+        st[k].requires_grad_(True)
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).double()
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    logits = orc.unet_forward(x, st, training=True)
+    ld = orc.dice_loss(logits, t, names)
+    ld["total_loss"].backward()
+    close(logits.detach(), g[f"{name}.logits"], 1e-4, 1e-4)
+    close([float(v) for v in ld.values()], g[f"{name}.loss"], 1e-5, 1e-6)
+    assert list(g[f"{name}.grad_keys"]) == keys
+    norms = np.array([float(st[k].grad.double().norm()) for k in keys])
+    is_cb = np.array([k.endswith(".0.bias") and k != "out_conv.bias" for k in keys])
+    close(norms[~is_cb], g[f"{name}.grad_norms"][~is_cb], 1e-3, 1e-8)
+    assert norms[is_cb].max() < 1e-10 and g[f"{name}.grad_norms"][is_cb].max() < 1e-3   # analytically zero
+    samp = np.stack([st[k].grad.numpy().reshape(-1)[mg.sample_idx(st[k].numel())] for k in keys])
+    scale = np.array([float(st[k].grad.abs().max()) for k in keys])[:, None]
+    assert (np.abs(samp - g[f"{name}.grad_samples"])[~is_cb] / scale[~is_cb]).max() < 2e-3
+    close(st["out_conv.weight"].grad, g[f"{name}.grad.out_conv.weight"], 1e-3, 1e-6)
+    close(st["center_conv.cbr1.1.running_mean"].detach(), g[f"{name}.running_mean.center_conv.cbr1"], 1e-4, 1e-6)
+    close(st["center_conv.cbr1.1.running_var"].detach(), g[f"{name}.running_var.center_conv.cbr1"], 1e-4, 1e-6)
+    with torch.no_grad():
+        close(orc.unet_forward(x, st, training=False), g[f"{name}.eval_logits"], 1e-4, 1e-4)
+
+
+def test_pool_and_upsample(golden):
+    g = golden("pool_up")
+    x = dg.hash_normalish((2, 3, 8, 12), 31)
+    x = np.maximum(x, 0)
+    x[0, 0, :4, :4] = 0.5
+    x = T(x).requires_grad_(True)
+    y = orc.maxpool2x2(x)
+    y.backward(T(dg.hash_normalish((2, 3, 4, 6), 32)))
+    assert np.array_equal(y.detach().numpy(), g["pool.y"])
+    assert np.array_equal(x.grad.numpy(), g["pool.dx"])
+    for name, (h, w) in {"up_2": (2, 2), "up_5": (5, 5), "up_3x7": (3, 7)}.items():
+        x = T(dg.hash_normalish((2, 3, h, w), 33 + h)).requires_grad_(True)
+        skip = T(dg.hash_normalish((2, 2, 2 * h, 2 * w), 43 + h)).requires_grad_(True)
+        y = torch.cat([orc.upsample2x_bilinear(x), skip], dim=1)
+        y.backward(T(dg.hash_normalish(tuple(y.shape), 53 + h)))
+        close(y.detach(), g[f"{name}.y"], 1e-6, 1e-6)
+        close(x.grad, g[f"{name}.dx"], 1e-5, 1e-6)
+        assert np.array_equal(skip.grad.numpy(), g[f"{name}.dskip"])
+
+
+@pytest.mark.parametrize("name", list(mg.loss_cases()))
+def test_losses(golden, name):
+    g = golden("loss")
+    c = mg.loss_cases()[name]
+    x, t = mg.loss_inputs(c)
+    names = [f"c{i}" for i in range(1, c["C"])]
+    xl = T(x).requires_grad_(True)
+    ld = orc.dice_loss(xl, T(t), names)
+    assert list(ld.keys()) == names + ["total_loss"]
+    ld["total_loss"].backward()
+    close([float(v) for v in ld.values()], g[f"{name}.dice"], 1e-6, 1e-7)
+    close(xl.grad, g[f"{name}.dice_dlogits"], 1e-4, 1e-9)
+    ce = orc.ce_map(T(x), T(t))
+    close(ce, g[f"{name}.ce_map"], 1e-5, 1e-6)
+    # Focal_Loss (loss_fn.py:204-217) rebuilt from the CE map pins that map through the reference class
+    pt = torch.exp(-ce)
+    focal = 0.25 * ((1 - pt) ** 2) * ce
+    vals = [float(focal[T(t) == i].mean()) if (t == i).any() else float("nan") for i in range(1, c["C"])]
+    ref = g[f"{name}.focal"]
+    np.testing.assert_allclose(vals, ref[:-1], rtol=1e-5, atol=1e-7, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", list(mg.metric_cases()))
+def test_metrics_bit_exact(golden, name):
+    g = golden("metrics")
+    c = mg.metric_cases()[name]
+    x, t = mg.metric_inputs(c)
+    cm = orc.confusion_counts(T(x), T(t))
+    tp, fn, fp, tn = orc._counts_to_onehot_terms(cm, c["n"] + 1)
+    for a, k in ((tp, "TP"), (fn, "FN"), (fp, "FP"), (tn, "TN")):
+        assert np.array_equal(a, g[f"{name}.{k}"])
+    m = orc.metrics_from_counts(cm, c["n"])
+    assert m.dtype == np.float64 and m.shape == (6, c["n"] + 1)
+    assert np.array_equal(m, g[f"{name}.matrix"]), (m - g[f"{name}.matrix"])
+
+
+def test_train_steps(golden):
+    g = golden("train")
+    c = mg.train_case()
+    st = orc.make_state(c["cin"], c["ncls"], base=8, seed=c["seed"], dtype=torch.float64)
+    ts = orc.TrainState(st)
+    names = ["a", "b", "c"]
+    losses = np.zeros(4)
+    mets = np.zeros((6, 4))
+    batches = mg.train_batches(c)
+    for x, t in batches:
+        l, m, _ = orc.train_step(ts, T(x).double(), T(t), names, lr=c["lr"])
+        losses += np.array(l)
+        mets += m
+    mets /= len(batches)
+    close(losses, g["train.losses"], 1e-5, 1e-6)
+    close(mets, g["train.metrics"], 1e-6, 1e-7)
+    assert list(g["train.keys"]) == list(st.keys())
+    # conv biases have an analytically zero gradient: AdamW turns their round-off
+    # noise into +-lr moves, so they are not comparable between implementations.
+    keep = np.array([not (k.endswith(".0.bias") and k != "out_conv.bias") for k in st])
+    sums = np.array([float(v.detach().double().sum()) for v in st.values()])
+    # AdamW's first steps move every element by about +-lr whatever the gradient's size,
+    # so an element whose gradient is round-off small may legitimately land 2*lr*steps away:
+    # bound the sums by a few such flips and require almost all elements to agree closely.
+    flip = 2 * c["lr"] * c["steps"]
+    assert np.abs(sums[keep] - g["train.param_sums"][keep]).max() < 4 * flip
+    for k in ("out_conv.weight", "encoder1.cbr1.0.weight"):
+        d = np.abs(st[k].detach().numpy() - g["train." + k])
+        assert d.max() <= flip + 1e-5 and (d < 1e-5).mean() > 0.95, (k, d.max(), (d < 1e-5).mean())
+    # evaluate(): eval-mode forward with the trained running statistics
+    el = np.zeros(4)
+    em = np.zeros((6, 4))
+    with torch.no_grad():
+        for x, t in batches:
+            lg = orc.unet_forward(T(x).double(), st, training=False)
+            el += np.array([float(v) for v in orc.dice_loss(lg, T(t), names).values()])
+            em += orc.metrics_update(lg, T(t), names)
+    # eval mode sees the (noise-driven) conv biases through the running means: looser bound
+    close(el, g["eval.losses"], 1e-3, 1e-5)
+    close(em / len(batches), g["eval.metrics"], 1e-2, 5e-3)
+
+
+def test_dp_emulation(golden):
+    g = golden("dp")
+    c = dict(B=4, cin=1, ncls=4, hw=32, seed=81)
+    x = dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)
+    t = dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)
+    grads, losses = None, []
+    for r in range(2):
+        st = orc.make_state(c["cin"], c["ncls"], base=8, seed=c["seed"])
+        keys = orc.param_keys(st)
+        for k in keys:
+            st[k].requires_grad_(True)
+        sl = slice(2 * r, 2 * r + 2)
+        ld = orc.dice_loss(orc.unet_forward(T(x[sl]), st), T(t[sl]), ["a", "b", "c"])
+        ld["total_loss"].backward()
+        losses.append(float(ld["total_loss"]))
+        gr = [st[k].grad.double().numpy() for k in keys]
+        grads = gr if grads is None else [a + b for a, b in zip(grads, gr)]
+    close(losses, g["dp.shard_losses"], 1e-5, 1e-6)
+    close([np.sqrt(((a / 2) ** 2).sum()) for a in grads], g["dp.grad_norms"], 2e-3, 1e-7)
+
+
+def test_slide(golden):
+    g = golden("slide")
+    model = mg.StubSegModel()
+    for name, c in mg.slide_cases().items():
+        img = (dg.hash_u64((c["h"], c["w"], 3), c["seed"]) % np.uint64(256)).astype(np.uint8)
+        padded, pads = orc.slide_pad(img, c["window"], c["stride"])
+        assert tuple(pads) == tuple(g[f"{name}.pads"])
+        pos = orc.slide_positions(padded.shape[0], padded.shape[1], c["window"], c["stride"])
+        assert np.array_equal(np.array(pos), g[f"{name}.positions"])
+        maps = []
+        for (y0, y1, x0, x1) in pos:
+            tile = torch.from_numpy(padded[y0:y1, x0:x1]).permute(2, 0, 1).float() / 255.0
+            maps.append(torch.argmax(model(tile[None]), dim=1)[0].numpy())
+        res = orc.slide_blend(maps, pos, padded.shape[:2], img.shape[:2], c["window"])
+        assert np.array_equal(res, g[f"{name}.result"])
+    for (h, w, win, s, n_tiles, n_unique) in [(4096, 4096, 1024, 512, 64, 49), (4096, 4096, 256, 128, 1024, 961)]:
+        pos = orc.slide_positions(h, w, win, s)
+        assert np.array_equal(np.array(pos), g[f"slide_pos_{h}x{w}_{win}_{s}.positions"])
+        assert len(pos) == n_tiles and len(set(pos)) == n_unique
