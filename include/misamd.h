@@ -1,0 +1,184 @@
+/*
+ * misamd — C-ABI of the MI355X (gfx950) U-Net training hot path.
+ *
+ * The reference project (Runner-xc/Medical_image_segmentation) is pure Python on
+ * torch ATen and has no FFI of its own; each entry point below replaces the ATen
+ * call sequence at the cited reference lines.  Paths are relative to the
+ * reference checkout.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; the library never
+ *     allocates, frees or synchronises: the caller owns all memory (workspaces
+ *     included, sized by the *_workspace_bytes queries) and passes the HIP stream
+ *     the work is enqueued on (hipStream_t as void*; NULL = default stream);
+ *   - activations are channels-last:  x[b][y][x][c]  ("NHWC"), element type given
+ *     by a mis_dtype (float32 or bfloat16); all accumulation is float32;
+ *   - parameters and their gradients are float32 in the reference's layouts
+ *     (conv weight [Cout][Cin][3][3], as nn.Conv2d stores it);
+ *   - targets are int64 class indices [B][H][W], counts are int64;
+ *   - every function returns 0 on success or a mis_status; mis_last_error() gives
+ *     a thread-local message.  The Python host raises RuntimeError on non-zero,
+ *     matching the reference's exception-based error convention.
+ */
+#ifndef MISAMD_H
+#define MISAMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mis_stream_t;
+
+enum mis_status {
+  MIS_OK = 0,
+  MIS_ERR_ARG = 1,          /* bad shape / null pointer / unsupported size */
+  MIS_ERR_LAUNCH = 2,       /* hipLaunch / runtime error */
+  MIS_ERR_UNSUPPORTED = 3   /* valid request the library has no kernel for */
+};
+
+enum mis_dtype { MIS_F32 = 0, MIS_BF16 = 1 };
+
+/* library / build probe */
+int         mis_version(void);              /* MAJOR*10000 + MINOR*100 + PATCH */
+const char* mis_arch(void);                 /* "gfx950" */
+const char* mis_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Loss + metrics: one pass over the logits.                                   */
+/* Replaces utils/loss_fn.py:72-83 (softmax, one_hot, three pooled sums, Dice), */
+/* utils/loss_fn.py:199-203 (per-pixel CE map, label_smoothing 1e-7,            */
+/* ignore_index 0) and utils/metrics.py:31-34,44-46,87-97 (argmax, one_hot,     */
+/* TP/FN/FP/TN counting).                                                       */
+/*                                                                              */
+/* logits element (b, c, pixel) is read at  b*stride_b + c*stride_c + pixel*stride_p */
+/* (elements), so both channels-last (stride_c=1, stride_p=C) and the           */
+/* reference's NCHW (stride_c=H*W, stride_p=1) layouts are accepted.            */
+/*                                                                              */
+/* sums    float32 [3][C]: I_c = sum p_c*[t==c], P_c = sum p_c, T_c = sum [t==c] */
+/*         over (B,H,W) with p = softmax(logits) (class 0 included; the Dice     */
+/*         loss ignores it).  May be NULL.                                       */
+/* ce_map  float32 [B][H][W] or NULL.                                            */
+/* cm      int64 [B][C][C], cm[b][t][p] = #pixels with target t and              */
+/*         argmax(logits) = p (first maximum on ties; NaN counts as maximal).    */
+/*         May be NULL.  Zeroed by the call.                                     */
+/* status  int32 [1] device word: set non-zero if a target is outside [0, C).    */
+/* 2 <= C <= 16.                                                                 */
+size_t mis_loss_metrics_workspace_bytes(int B, int C, int HW);
+int mis_loss_metrics_fwd(const void* logits, int dtype, int64_t stride_b, int64_t stride_c, int64_t stride_p,
+                         const int64_t* target, int B, int C, int HW,
+                         float* sums, float* ce_map, int64_t* cm, int32_t* status,
+                         void* workspace, mis_stream_t stream);
+
+/* Dice loss values from the pooled sums — utils/loss_fn.py:81-83.               */
+/* losses float32 [C]: losses[i] = 1 - 2 I_{i+1} / (P_{i+1} + T_{i+1} + smooth)  */
+/* for i < C-1 and losses[C-1] = total = sum_i losses[i] / C.                    */
+int mis_dice_from_sums(const float* sums, int C, float smooth, float* losses, mis_stream_t stream);
+
+/* Gradient of  sum_i w[i]*losses[i]  (+ sum over pixels of dce*ce_map when dce  */
+/* is not NULL) with respect to the logits; autograd of loss_fn.py:72-83,199-203. */
+/* w float32 [C] device (upstream gradient of each entry of `losses`);           */
+/* dlogits has the logits' dtype and strides.                                    */
+int mis_loss_bwd(const void* logits, int dtype, int64_t stride_b, int64_t stride_c, int64_t stride_p,
+                 const int64_t* target, int B, int C, int HW,
+                 const float* sums, const float* w, float smooth, const float* dce,
+                 void* dlogits, mis_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Down / Up: nn.MaxPool2d(2,2) (model/unet.py:19,48,52,56,60) and             */
+/* nn.Upsample(2,'bilinear',align_corners=True) + torch.cat([up, skip], 1)      */
+/* (model/unet.py:20,66-67,71-72,76-77,80-81).  Channels-last, H and W even.    */
+int mis_maxpool2x2_fwd(const void* x, int dtype, int B, int H, int W, int C, void* y, mis_stream_t stream);
+/* dx = gradient routed to the first maximum of each window (row-major scan,    */
+/* strict '>'), zero elsewhere; x is the forward input.                         */
+int mis_maxpool2x2_bwd(const void* x, const void* dy, int dtype, int B, int H, int W, int C,
+                       void* dx, mis_stream_t stream);
+/* out[b][2h][2w][0:Cup] = bilinear(low), out[...][Cup:Cup+Cskip] = skip.        */
+int mis_upsample2x_cat_fwd(const void* low, const void* skip, int dtype, int B, int h, int w,
+                           int Cup, int Cskip, void* out, mis_stream_t stream);
+/* dlow[b][h][w][Cup] gathered from dout[..., 0:Cup]; dskip = dout[..., Cup:].   */
+int mis_upsample2x_cat_bwd(const void* dout, int dtype, int B, int h, int w, int Cup, int Cskip,
+                           void* dlow, void* dskip, mis_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* DoubleConv building block: Conv2d(3x3, pad 1, bias) -> BatchNorm2d -> ReLU   */
+/* (model/utils/modules.py:86-94,97-99).                                        */
+/*                                                                              */
+/* mis_pack_conv3x3_weights: float32 [Cout][Cin][3][3] -> the two operand       */
+/* layouts the conv kernels read, in the activation dtype:                      */
+/*   w_fwd [9][Cout][Cin]  (tap = ky*3+kx)                                       */
+/*   w_dgrad [9][Cin][Cout] with taps mirrored (for dX = conv(dZ, W^T flipped)). */
+/* Either output may be NULL.                                                   */
+int mis_pack_conv3x3_weights(const float* w, int Cout, int Cin, int dtype, void* w_fwd, void* w_dgrad,
+                             mis_stream_t stream);
+
+/* z = conv3x3(x, w) + bias (bias may be NULL), channels-last, same H,W.        */
+/* If stats is not NULL it receives float32 [2][Cout]: sum z and sum z^2 over   */
+/* (B,H,W), taken from the float32 accumulators (before any rounding to bf16);  */
+/* it needs the workspace.  Used for the forward conv (w_fwd, Cin->Cout) and,   */
+/* with w_dgrad and the channel counts swapped, for the data gradient.          */
+size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int mis_conv3x3_fwd(const void* x, const void* w_packed, const float* bias, int dtype,
+                    int B, int H, int W, int Cin, int Cout,
+                    void* z, float* stats, void* workspace, mis_stream_t stream);
+
+/* dW float32 [Cout][Cin][3][3] = sum_{b,y,x} dz[b,y,x,co] * x[b,y+ky-1,x+kx-1,ci] */
+/* (autograd of nn.Conv2d wrt its weight).  Overwrites dw.                       */
+size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int mis_conv3x3_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout,
+                      float* dw, void* workspace, mis_stream_t stream);
+
+/* Training-mode BatchNorm2d statistics -> per-channel affine + running stats.   */
+/* stats float32 [2][C] (sum, sum of squares over n = B*H*W values per channel). */
+/* scale_shift float32 [2][C]: y = z*scale + shift with                          */
+/*   scale = gamma / sqrt(var_biased + eps), shift = beta - mean*scale.           */
+/* mean_rstd float32 [2][C] saved for the backward.  running_mean/var (may be    */
+/* NULL) are updated with `momentum` and the UNBIASED variance, as               */
+/* nn.BatchNorm2d does; num_batches_tracked (int64[1], may be NULL) += 1.        */
+int mis_bn_finalize(const float* stats, int C, int64_t n, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, float* scale_shift, float* mean_rstd, mis_stream_t stream);
+/* Eval-mode affine from the running statistics.                                 */
+int mis_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma,
+                       const float* beta, int C, float eps, float* scale_shift, mis_stream_t stream);
+/* a = relu(z*scale + shift); n_pix = B*H*W.                                     */
+int mis_bn_relu_apply(const void* z, int dtype, int64_t n_pix, int C, const float* scale_shift,
+                      void* a, mis_stream_t stream);
+/* Backward of a = relu(bn(z)) in training mode; the ReLU mask is recomputed from  */
+/* z (y = xhat*gamma + beta > 0), so the activation itself is not an input.       */
+/* Pass 1 reduces  sums[0][c] = sum dy, sums[1][c] = sum dy*xhat  with             */
+/*   dy = da*[y>0], xhat = (z-mean)*rstd;  dbeta = sums[0], dgamma = sums[1].      */
+/* Pass 2 writes  dz = gamma*rstd*(dy - sums0/n - xhat*sums1/n).                    */
+size_t mis_bn_relu_bwd_workspace_bytes(int64_t n_pix, int C);
+int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_pix, int C,
+                           const float* mean_rstd, const float* gamma, const float* beta,
+                           float* sums, void* workspace, mis_stream_t stream);
+int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, int C,
+                       const float* mean_rstd, const float* gamma, const float* beta, const float* sums,
+                       void* dz, mis_stream_t stream);
+/* Per-channel sum over pixels of a channels-last tensor (conv bias gradient).   */
+size_t mis_channel_sum_workspace_bytes(int64_t n_pix, int C);
+int mis_channel_sum(const void* x, int dtype, int64_t n_pix, int C, float* out, void* workspace,
+                    mis_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Output layer nn.Conv2d(base, n_classes, 1) — model/unet.py:44,84.            */
+/* w float32 [Cout][Cin], bias float32 [Cout].                                   */
+int mis_conv1x1_fwd(const void* x, int dtype, int64_t n_pix, int Cin, int Cout, const float* w,
+                    const float* bias, void* y, mis_stream_t stream);
+size_t mis_conv1x1_bwd_workspace_bytes(int64_t n_pix, int Cin, int Cout);
+/* dx (same dtype), dw float32 [Cout][Cin], dbias float32 [Cout]; dx may be NULL. */
+int mis_conv1x1_bwd(const void* x, const void* dy, int dtype, int64_t n_pix, int Cin, int Cout,
+                    const float* w, void* dx, float* dw, float* dbias, void* workspace, mis_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Layout / dtype helpers for the model boundary (NCHW float32 images in,       */
+/* channels-last activations inside).                                           */
+int mis_nchw_f32_to_nhwc(const float* x, int B, int C, int H, int W, int dtype, void* y, mis_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISAMD_H */

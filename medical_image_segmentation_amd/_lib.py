@@ -1,0 +1,80 @@
+"""ctypes binding of libmisamd.so (the C-ABI declared in include/misamd.h).
+
+The shared library is built in-tree by `make -C medical_image_segmentation_amd/csrc`
+(or `__graft_entry__.build()`).  There is NO fallback: if the library is missing or a
+call fails, a RuntimeError is raised — the reference signals errors by exceptions too
+(e.g. train.py:211).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmisamd.so")
+
+F32, BF16 = 0, 1
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/misamd.h one to one
+PROTOTYPES = {
+    "mis_version": (_i, []),
+    "mis_arch": (C.c_char_p, []),
+    "mis_last_error": (C.c_char_p, []),
+    "mis_loss_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mis_loss_metrics_fwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_dice_from_sums": (_i, [_vp, _i, _f, _vp, _vp]),
+    "mis_loss_bwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "mis_maxpool2x2_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_upsample2x_cat_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_upsample2x_cat_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_pack_conv3x3_weights": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_conv3x3_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "mis_conv3x3_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "mis_conv3x3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_bn_finalize": (_i, [_vp, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_eval_affine": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
+    "mis_bn_relu_apply": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
+    "mis_bn_relu_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "mis_bn_relu_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_channel_sum_workspace_bytes": (_sz, [_i64, _i]),
+    "mis_channel_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
+    "mis_conv1x1_fwd": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "mis_conv1x1_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "mis_conv1x1_bwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_nchw_f32_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the library once; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(there is no CPU or eager fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Calls a status-returning entry point; non-zero -> RuntimeError(mis_last_error())."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.mis_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (status {rc}): {msg}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,285 @@
+// BatchNorm2d (training statistics) + ReLU around the conv kernels, and the per-channel
+// reductions they need.  The conv kernel emits sum(z) and sum(z^2); bn_finalize turns them
+// into a per-channel affine (scale, shift) plus the saved (mean, rstd) and updates the
+// running statistics the way nn.BatchNorm2d does (momentum, unbiased variance).
+//
+// Roofline: HBM for the elementwise passes.  Algorithmic bytes per element:
+//   bn_relu_apply     read z + write a            = 2*sizeof(T)
+//   bn_relu_bwd_reduce read z + da                = 2*sizeof(T)
+//   bn_relu_bwd_dz    read z + da, write dz       = 3*sizeof(T)
+#include "common.h"
+#include "vec.h"
+#include "reduce.h"
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int n, int64_t stride,
+                                       float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; i++) s += (double)partials[(int64_t)i * stride + j];
+  out[j] = (float)s;
+}
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double inv_n, double unbias,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   int64_t* __restrict__ nbt, float* __restrict__ scale_shift,
+                                   float* __restrict__ mean_rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  const double mean = (double)stats[c] * inv_n;
+  double var = (double)stats[C + c] * inv_n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - (float)mean * sc;
+  if (mean_rstd) {
+    mean_rstd[c] = (float)mean;
+    mean_rstd[C + c] = rstd;
+  }
+  if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, int C, float eps,
+                                      float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - rm[c] * sc;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(EW_THREADS) void bn_relu_apply_kernel(const T* __restrict__ z, T* __restrict__ a,
+                                                                   int64_t n_vec, int C,
+                                                                   const float* __restrict__ scale_shift) {
+  extern __shared__ float ss[];   // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) ss[i] = scale_shift[i];
+  __syncthreads();
+  const int CV = C / V;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int c0 = (int)(i % CV) * V;
+    float v[V];
+    vload<T, V>(z + i * V, v);
+#pragma unroll
+    for (int k = 0; k < V; k++) v[k] = fmaxf(v[k] * ss[c0 + k] + ss[C + c0 + k], 0.f);
+    vstore<T, V>(a + i * V, v);
+  }
+}
+
+template <typename T, int V>
+struct BnBwdReduce {
+  static constexpr int NOUT = 2;
+  const T* z;
+  const T* da;
+  const float* mean_rstd;
+  const float* gamma;
+  const float* beta;
+  int C;
+  __device__ __forceinline__ void load(int64_t pix, int c0, float (&acc)[2][V]) const {
+    float zv[V], gv[V];
+    vload<T, V>(z + pix * C + c0, zv);
+    vload<T, V>(da + pix * C + c0, gv);
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      const float xh = (zv[k] - mean_rstd[c0 + k]) * mean_rstd[C + c0 + k];
+      const float y = xh * gamma[c0 + k] + beta[c0 + k];
+      const float dy = (y > 0.f) ? gv[k] : 0.f;
+      acc[0][k] += dy;
+      acc[1][k] += dy * xh;
+    }
+  }
+};
+
+template <typename T, int V>
+struct ChannelSum {
+  static constexpr int NOUT = 1;
+  const T* x;
+  int C;
+  __device__ __forceinline__ void load(int64_t pix, int c0, float (&acc)[1][V]) const {
+    float v[V];
+    vload<T, V>(x + pix * C + c0, v);
+#pragma unroll
+    for (int k = 0; k < V; k++) acc[0][k] += v[k];
+  }
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __restrict__ z, const T* __restrict__ da,
+                                                                    T* __restrict__ dz, int64_t n_vec, int C,
+                                                                    float inv_n, const float* __restrict__ mean_rstd,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta,
+                                                                    const float* __restrict__ sums) {
+  extern __shared__ float prm[];   // [6][C]: mean, rstd, gamma, beta, sum_dy/n, sum_dy_xhat/n
+  for (int i = threadIdx.x; i < C; i += EW_THREADS) {
+    prm[i] = mean_rstd[i];
+    prm[C + i] = mean_rstd[C + i];
+    prm[2 * C + i] = gamma[i];
+    prm[3 * C + i] = beta[i];
+    prm[4 * C + i] = sums[i] * inv_n;
+    prm[5 * C + i] = sums[C + i] * inv_n;
+  }
+  __syncthreads();
+  const int CV = C / V;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int c0 = (int)(i % CV) * V;
+    float zv[V], gv[V], o[V];
+    vload<T, V>(z + i * V, zv);
+    vload<T, V>(da + i * V, gv);
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      const int c = c0 + k;
+      const float xh = (zv[k] - prm[c]) * prm[C + c];
+      const float y = xh * prm[2 * C + c] + prm[3 * C + c];
+      const float dy = (y > 0.f) ? gv[k] : 0.f;
+      o[k] = prm[2 * C + c] * prm[C + c] * (dy - prm[4 * C + c] - xh * prm[5 * C + c]);
+    }
+    vstore<T, V>(dz + i * V, o);
+  }
+}
+
+template <typename T>
+int apply_t(const void* z, void* a, int64_t n_pix, int C, const float* ss, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  const int64_t n = n_pix * C;
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (pick_vec<T>(C, z, a) == N)
+    bn_relu_apply_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>((const T*)z, (T*)a, n / N, C, ss);
+  else
+    bn_relu_apply_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>((const T*)z, (T*)a, n, C, ss);
+  return 0;
+}
+
+template <typename T>
+int bwd_reduce_t(const void* z, const void* da, int64_t n_pix, int C, const float* mean_rstd, const float* gamma,
+                 const float* beta, float* sums, void* ws, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  if (pick_vec<T>(C, z, da) == N) {
+    BnBwdReduce<T, N> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C};
+    launch_channel_reduce<N>(f, n_pix, C, (float*)ws, sums, st);
+  } else {
+    BnBwdReduce<T, 1> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C};
+    launch_channel_reduce<1>(f, n_pix, C, (float*)ws, sums, st);
+  }
+  return 0;
+}
+
+template <typename T>
+int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, const float* mean_rstd,
+             const float* gamma, const float* beta, const float* sums, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  const int64_t n = n_pix * C;
+  const size_t lds = 6 * (size_t)C * sizeof(float);
+  const float inv_n = (float)(1.0 / (double)n_pix);
+  if (pick_vec<T>(C, z, da, dz) == N)
+    bn_relu_bwd_dz_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>(
+        (const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n, mean_rstd, gamma, beta, sums);
+  else
+    bn_relu_bwd_dz_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>(
+        (const T*)z, (const T*)da, (T*)dz, n, C, inv_n, mean_rstd, gamma, beta, sums);
+  return 0;
+}
+
+template <typename T>
+int chan_sum_t(const void* x, int64_t n_pix, int C, float* out, void* ws, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  if (pick_vec<T>(C, x) == N) {
+    ChannelSum<T, N> f{(const T*)x, C};
+    launch_channel_reduce<N>(f, n_pix, C, (float*)ws, out, st);
+  } else {
+    ChannelSum<T, 1> f{(const T*)x, C};
+    launch_channel_reduce<1>(f, n_pix, C, (float*)ws, out, st);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mis_bn_finalize(const float* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* scale_shift, float* mean_rstd, mis_stream_t stream) {
+  MIS_REQUIRE(stats && gamma && beta && scale_shift, "bn_finalize: null pointer");
+  MIS_REQUIRE(C >= 1 && n >= 1, "bn_finalize: bad shape C=%d n=%lld", C, (long long)n);
+  const double unbias = n > 1 ? (double)n / (double)(n - 1) : 1.0;
+  bn_finalize_kernel<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(stats, C, 1.0 / (double)n, unbias, gamma, beta,
+                                                                    eps, momentum, running_mean, running_var,
+                                                                    num_batches_tracked, scale_shift, mean_rstd);
+  MIS_CHECK_LAUNCH("bn_finalize_kernel");
+  return MIS_OK;
+}
+
+int mis_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                       int C, float eps, float* scale_shift, mis_stream_t stream) {
+  MIS_REQUIRE(running_mean && running_var && gamma && beta && scale_shift && C >= 1, "bn_eval_affine: bad arguments");
+  bn_eval_affine_kernel<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(running_mean, running_var, gamma, beta, C, eps,
+                                                                       scale_shift);
+  MIS_CHECK_LAUNCH("bn_eval_affine_kernel");
+  return MIS_OK;
+}
+
+int mis_bn_relu_apply(const void* z, int dtype, int64_t n_pix, int C, const float* scale_shift, void* a,
+                      mis_stream_t stream) {
+  MIS_REQUIRE(z && a && scale_shift && n_pix >= 1 && C >= 1 && C <= 4096, "bn_relu_apply: bad arguments");
+  if (dtype == MIS_F32) apply_t<float>(z, a, n_pix, C, scale_shift, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) apply_t<bf16>(z, a, n_pix, C, scale_shift, (hipStream_t)stream);
+  else MIS_REQUIRE(false, "bn_relu_apply: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("bn_relu_apply_kernel");
+  return MIS_OK;
+}
+
+size_t mis_bn_relu_bwd_workspace_bytes(int64_t n_pix, int C) { return red_workspace_bytes(2, C); }
+
+int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
+                           const float* gamma, const float* beta, float* sums, void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(z && da && mean_rstd && gamma && beta && sums && workspace, "bn_relu_bwd_reduce: null pointer");
+  MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_reduce: bad shape");
+  if (dtype == MIS_F32) {
+    MIS_REQUIRE(C % 4 == 0 ? C / 4 <= 256 : C <= 256, "bn_relu_bwd_reduce: C=%d too large for this layout", C);
+    bwd_reduce_t<float>(z, da, n_pix, C, mean_rstd, gamma, beta, sums, workspace, (hipStream_t)stream);
+  } else if (dtype == MIS_BF16) {
+    MIS_REQUIRE(C % 8 == 0 ? C / 8 <= 256 : C <= 256, "bn_relu_bwd_reduce: C=%d too large for this layout", C);
+    bwd_reduce_t<bf16>(z, da, n_pix, C, mean_rstd, gamma, beta, sums, workspace, (hipStream_t)stream);
+  } else MIS_REQUIRE(false, "bn_relu_bwd_reduce: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("bn_relu_bwd_reduce");
+  return MIS_OK;
+}
+
+int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
+                       const float* gamma, const float* beta, const float* sums, void* dz, mis_stream_t stream) {
+  MIS_REQUIRE(z && da && mean_rstd && gamma && beta && sums && dz, "bn_relu_bwd_dz: null pointer");
+  MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_dz: bad shape");
+  if (dtype == MIS_F32) bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) bwd_dz_t<bf16>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, (hipStream_t)stream);
+  else MIS_REQUIRE(false, "bn_relu_bwd_dz: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("bn_relu_bwd_dz_kernel");
+  return MIS_OK;
+}
+
+size_t mis_channel_sum_workspace_bytes(int64_t n_pix, int C) { return red_workspace_bytes(1, C); }
+
+int mis_channel_sum(const void* x, int dtype, int64_t n_pix, int C, float* out, void* workspace,
+                    mis_stream_t stream) {
+  MIS_REQUIRE(x && out && workspace && n_pix >= 1 && C >= 1, "channel_sum: bad arguments");
+  if (dtype == MIS_F32) {
+    MIS_REQUIRE(C % 4 == 0 ? C / 4 <= 256 : C <= 256, "channel_sum: C=%d too large for this layout", C);
+    chan_sum_t<float>(x, n_pix, C, out, workspace, (hipStream_t)stream);
+  } else if (dtype == MIS_BF16) {
+    MIS_REQUIRE(C % 8 == 0 ? C / 8 <= 256 : C <= 256, "channel_sum: C=%d too large for this layout", C);
+    chan_sum_t<bf16>(x, n_pix, C, out, workspace, (hipStream_t)stream);
+  } else MIS_REQUIRE(false, "channel_sum: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("channel_sum");
+  return MIS_OK;
+}
+
+}  // extern "C"

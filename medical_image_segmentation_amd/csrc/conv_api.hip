@@ -1,0 +1,52 @@
+// Public 3x3 convolution entry points: pick the matrix-core kernel when the shape
+// allows it, else the vector-ALU kernel.  MIS_CONV_FORCE_DIRECT=1 in the environment
+// forces the vector-ALU kernels (used by the tests to cross-check the two paths).
+#include "conv_internal.h"
+#include <stdlib.h>
+
+static bool force_direct() {
+  const char* e = getenv("MIS_CONV_FORCE_DIRECT");
+  return e && e[0] == '1';
+}
+
+extern "C" {
+
+size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
+  size_t a = conv3x3_direct_workspace_bytes((int64_t)B * H * W, Cout);
+  size_t b = conv3x3_mfma_workspace_bytes(MIS_BF16, B, H, W, Cin, Cout);
+  size_t c = conv3x3_mfma_workspace_bytes(MIS_F32, B, H, W, Cin, Cout);
+  size_t m = a > b ? a : b;
+  return (m > c ? m : c) + 256;
+}
+
+int mis_conv3x3_fwd(const void* x, const void* w_packed, const float* bias, int dtype, int B, int H, int W, int Cin,
+                    int Cout, void* z, float* stats, void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(x && w_packed && z, "conv3x3_fwd: null pointer");
+  MIS_REQUIRE(!stats || workspace, "conv3x3_fwd: stats requested without a workspace");
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_fwd: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_fwd: bad dtype %d", dtype);
+  MIS_REQUIRE((int64_t)B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < ((int64_t)1 << 40), "conv3x3_fwd: tensor too large");
+  if (!force_direct() && conv3x3_mfma_supported(dtype, B, H, W, Cin, Cout))
+    return conv3x3_mfma_fwd(x, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace, (hipStream_t)stream);
+  return conv3x3_direct_fwd(x, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace, (hipStream_t)stream);
+}
+
+size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
+  size_t b = conv3x3_wgrad_mfma_workspace_bytes(MIS_BF16, B, H, W, Cin, Cout);
+  size_t c = conv3x3_wgrad_mfma_workspace_bytes(MIS_F32, B, H, W, Cin, Cout);
+  return (b > c ? b : c) + 256;
+}
+
+int mis_conv3x3_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
+                      void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(x && dz && dw, "conv3x3_wgrad: null pointer");
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_wgrad: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_wgrad: bad dtype %d", dtype);
+  if (!force_direct() && workspace && conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout))
+    return conv3x3_wgrad_mfma(x, dz, dtype, B, H, W, Cin, Cout, dw, workspace, (hipStream_t)stream);
+  return conv3x3_direct_wgrad(x, dz, dtype, B, H, W, Cin, Cout, dw, (hipStream_t)stream);
+}
+
+}  // extern "C"

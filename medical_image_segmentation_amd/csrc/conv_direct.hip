@@ -1,0 +1,451 @@
+// Vector-ALU convolution kernels: the image-facing first layer (Cin = 1 or 3, where the
+// GEMM K dimension is too short for the matrix cores), the 1x1 output layer, the weight
+// packers, and a shape-agnostic 3x3 fallback used for channel counts the MFMA kernels do
+// not take.  Channels-last activations, float32 accumulation.
+//
+// Roofline: HBM for the production uses (first layer: read Cin + write Cout per pixel;
+// 1x1: read Cin + write Cout per pixel).
+#include "common.h"
+#include "vec.h"
+#include "reduce.h"
+
+namespace {
+
+constexpr int CD_THREADS = 256;
+constexpr int CO_T = 8;          // output channels per thread
+constexpr int CI_CHUNK = 32;     // input channels staged in LDS per pass
+
+// ---------------------------------------------------------------------------------
+// weight packers
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_w3x3_kernel(const float* __restrict__ w, int Cout, int Cin, T* __restrict__ w_fwd,
+                                 T* __restrict__ w_dgrad) {
+  const int64_t n = (int64_t)Cout * Cin * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const int ci = (int)((i / 9) % Cin);
+    const int co = (int)(i / (9 * (int64_t)Cin));
+    const float v = w[i];
+    if (w_fwd) w_fwd[((int64_t)tap * Cout + co) * Cin + ci] = from_f32<T>(v);
+    if (w_dgrad) w_dgrad[((int64_t)(8 - tap) * Cin + ci) * Cout + co] = from_f32<T>(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// direct 3x3 forward: one thread = one pixel x CO_T output channels
+// ---------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
+    const T* __restrict__ x, const T* __restrict__ wp /*[9][Cout][Cin]*/, const float* __restrict__ bias,
+    T* __restrict__ z, float* __restrict__ partials /*[gridDim.x][2][Cout] or null*/, int B, int H, int W, int Cin,
+    int Cout) {
+  __shared__ float wl[9][CI_CHUNK][CO_T];
+  __shared__ float red[2 * CO_T * (CD_THREADS / 64)];
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * CO_T;
+  const int64_t n_pix = (int64_t)B * H * W;
+  const int64_t pix = (int64_t)blockIdx.x * CD_THREADS + tid;
+  const bool valid = pix < n_pix;
+  int px = 0, py = 0;
+  if (valid) {
+    px = (int)(pix % W);
+    py = (int)((pix / W) % H);
+  }
+  float acc[CO_T];
+#pragma unroll
+  for (int j = 0; j < CO_T; j++) acc[j] = 0.f;
+
+  for (int c0 = 0; c0 < Cin; c0 += CI_CHUNK) {
+    const int cn = (Cin - c0 < CI_CHUNK) ? (Cin - c0) : CI_CHUNK;
+    __syncthreads();
+    for (int i = tid; i < 9 * CI_CHUNK * CO_T; i += CD_THREADS) {
+      const int j = i % CO_T, ci = (i / CO_T) % CI_CHUNK, tap = i / (CO_T * CI_CHUNK);
+      float v = 0.f;
+      if (ci < cn && co0 + j < Cout) v = to_f32(wp[((int64_t)tap * Cout + co0 + j) * Cin + c0 + ci]);
+      wl[tap][ci][j] = v;
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const T* xp = x + (pix + (int64_t)(tap / 3 - 1) * W + (tap % 3 - 1)) * Cin + c0;
+        for (int ci = 0; ci < cn; ci += V) {
+          float xv[V];
+          vload<T, V>(xp + ci, xv);
+#pragma unroll
+          for (int k = 0; k < V; k++)
+#pragma unroll
+            for (int j = 0; j < CO_T; j++) acc[j] += xv[k] * wl[tap][ci + k][j];
+        }
+      }
+    }
+  }
+  float st[2 * CO_T];
+#pragma unroll
+  for (int j = 0; j < CO_T; j++) {
+    const float b = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
+    acc[j] += b;
+    st[j] = valid ? acc[j] : 0.f;
+    st[CO_T + j] = valid ? acc[j] * acc[j] : 0.f;
+  }
+  if (valid) {
+    T* zp = z + pix * Cout + co0;
+    if (co0 + CO_T <= Cout && (Cout % CO_T) == 0 && sizeof(T) * CO_T >= 16) {
+      if constexpr (sizeof(T) == 2) {
+        vstore<T, CO_T>(zp, acc);
+      } else {
+        float lo[4] = {acc[0], acc[1], acc[2], acc[3]}, hi[4] = {acc[4], acc[5], acc[6], acc[7]};
+        vstore<T, 4>(zp, lo);
+        vstore<T, 4>(zp + 4, hi);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CO_T; j++)
+        if (co0 + j < Cout) zp[j] = from_f32<T>(acc[j]);
+    }
+  }
+  if (partials) {
+    block_sum<2 * CO_T>(st, red);
+    if (tid < 2 * CO_T) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * CO_T; i++) v = (tid == i) ? st[i] : v;
+      const int which = tid / CO_T, j = tid % CO_T;
+      if (co0 + j < Cout) partials[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + j] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// direct 3x3 weight gradient: grid (pixel blocks, Cout/CO_T, Cin); a thread walks pixels,
+// keeps 9 x CO_T accumulators for one input channel and the block adds them atomically.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const T* __restrict__ x,
+                                                                          const T* __restrict__ dz,
+                                                                          float* __restrict__ dw, int B, int H, int W,
+                                                                          int Cin, int Cout, int64_t pix_per_blk) {
+  __shared__ float red[9 * CO_T * (CD_THREADS / 64)];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int co0 = blockIdx.y * CO_T, ci = blockIdx.z;
+  const int64_t n_pix = (int64_t)B * H * W;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_blk;
+  int64_t p1 = p0 + pix_per_blk;
+  if (p1 > n_pix) p1 = n_pix;
+  float acc[9][CO_T];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int j = 0; j < CO_T; j++) acc[t][j] = 0.f;
+  for (int64_t pix = p0 + tid; pix < p1; pix += CD_THREADS) {
+    const int px = (int)(pix % W), py = (int)((pix / W) % H);
+    float g[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; j++) g[j] = (co0 + j < Cout) ? to_f32(dz[pix * Cout + co0 + j]) : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      float xv = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        xv = to_f32(x[(pix + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * Cin + ci]);
+#pragma unroll
+      for (int j = 0; j < CO_T; j++) acc[t][j] += xv * g[j];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int j = 0; j < CO_T; j++) {
+      const float s = wave_sum(acc[t][j]);
+      if (lane == 0) red[wid * 72 + t * CO_T + j] = s;
+    }
+  __syncthreads();
+  if (tid < 72) {
+    float s = 0.f;
+    for (int w = 0; w < CD_THREADS / 64; w++) s += red[w * 72 + tid];
+    const int t = tid / CO_T, j = tid % CO_T;
+    if (co0 + j < Cout) atomicAdd(&dw[((int64_t)(co0 + j) * Cin + ci) * 9 + t], s);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// 1x1 output convolution
+// ---------------------------------------------------------------------------------
+template <typename T, int V, int CO>
+__global__ __launch_bounds__(CD_THREADS) void conv1x1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, T* __restrict__ y,
+                                                                 int64_t n_pix, int Cin) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cin][CO]  (transposed: ci major)
+  for (int i = threadIdx.x; i < Cin * CO; i += CD_THREADS) wl[i] = w[(i % CO) * Cin + i / CO];
+  __syncthreads();
+  float bv[CO];
+#pragma unroll
+  for (int j = 0; j < CO; j++) bv[j] = bias ? bias[j] : 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * CD_THREADS + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * CD_THREADS) {
+    float acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; j++) acc[j] = bv[j];
+    for (int c = 0; c < Cin; c += V) {
+      float xv[V];
+      vload<T, V>(x + p * Cin + c, xv);
+#pragma unroll
+      for (int k = 0; k < V; k++)
+#pragma unroll
+        for (int j = 0; j < CO; j++) acc[j] += xv[k] * wl[(c + k) * CO + j];
+    }
+    vstore<T, CO>(y + p * CO, acc);
+  }
+}
+
+// Backward of the 1x1 conv: grid.y = Cin / V chunks.  Each thread: dx for its chunk, and
+// block partials of dW[:, chunk] (+ dbias in chunk 0).
+template <typename T, int V, int CO>
+__global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                 const float* __restrict__ w, T* __restrict__ dx,
+                                                                 float* __restrict__ partials, int64_t n_pix, int Cin,
+                                                                 int64_t pix_per_blk) {
+  // partials layout: [gridDim.x][CO*Cin + CO]
+  __shared__ float red[(CO * V + CO) * (CD_THREADS / 64)];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int c0 = blockIdx.y * V;
+  float wr[CO][V];
+#pragma unroll
+  for (int j = 0; j < CO; j++)
+#pragma unroll
+    for (int k = 0; k < V; k++) wr[j][k] = w[j * Cin + c0 + k];
+  float aw[CO][V], ab[CO];
+#pragma unroll
+  for (int j = 0; j < CO; j++) {
+    ab[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < V; k++) aw[j][k] = 0.f;
+  }
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_blk;
+  int64_t p1 = p0 + pix_per_blk;
+  if (p1 > n_pix) p1 = n_pix;
+  for (int64_t p = p0 + tid; p < p1; p += CD_THREADS) {
+    float g[CO], xv[V], d[V];
+    vload<T, CO>(dy + p * CO, g);
+    vload<T, V>(x + p * Cin + c0, xv);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CO; j++) {
+      ab[j] += g[j];
+#pragma unroll
+      for (int k = 0; k < V; k++) {
+        d[k] += g[j] * wr[j][k];
+        aw[j][k] += g[j] * xv[k];
+      }
+    }
+    if (dx) vstore<T, V>(dx + p * Cin + c0, d);
+  }
+  constexpr int NR = CO * V + CO;
+#pragma unroll
+  for (int j = 0; j < CO; j++) {
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      const float s = wave_sum(aw[j][k]);
+      if (lane == 0) red[wid * NR + j * V + k] = s;
+    }
+    const float s = wave_sum(ab[j]);
+    if (lane == 0) red[wid * NR + CO * V + j] = s;
+  }
+  __syncthreads();
+  if (tid < NR) {
+    float s = 0.f;
+    for (int w2 = 0; w2 < CD_THREADS / 64; w2++) s += red[w2 * NR + tid];
+    float* prow = partials + (int64_t)blockIdx.x * (CO * Cin + CO);
+    if (tid < CO * V) {
+      const int j = tid / V, k = tid % V;
+      prow[j * Cin + c0 + k] = s;
+    } else if (blockIdx.y == 0) {
+      prow[CO * Cin + (tid - CO * V)] = s;
+    }
+  }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int64_t HW) {
+  const int64_t n = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / HW, p = i % HW;
+    for (int c = 0; c < C; c++) y[i * C + c] = from_f32<T>(x[(b * C + c) * HW + p]);
+  }
+}
+
+constexpr int C1_MAX_BLOCKS = 512;
+
+template <typename T, int CO>
+int conv1x1_fwd_t(const void* x, int64_t n_pix, int Cin, const float* w, const float* bias, void* y, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  const size_t lds = (size_t)Cin * CO * sizeof(float);
+  const int grid = ew_grid(n_pix, CD_THREADS);
+  if (pick_vec<T>(Cin, x) == N)
+    conv1x1_fwd_kernel<T, N, CO><<<grid, CD_THREADS, lds, st>>>((const T*)x, w, bias, (T*)y, n_pix, Cin);
+  else
+    conv1x1_fwd_kernel<T, 1, CO><<<grid, CD_THREADS, lds, st>>>((const T*)x, w, bias, (T*)y, n_pix, Cin);
+  return 0;
+}
+
+template <typename T, int CO>
+int conv1x1_bwd_t(const void* x, const void* dy, int64_t n_pix, int Cin, const float* w, void* dx, float* dw,
+                  float* dbias, void* ws, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  int nblk = (int)((n_pix + CD_THREADS * 8 - 1) / (CD_THREADS * 8));
+  if (nblk > C1_MAX_BLOCKS) nblk = C1_MAX_BLOCKS;
+  if (nblk < 1) nblk = 1;
+  const int64_t ppb = (n_pix + nblk - 1) / nblk;
+  float* partials = (float*)ws;
+  if (pick_vec<T>(Cin, x, dx) == N)
+    conv1x1_bwd_kernel<T, N, CO><<<dim3(nblk, Cin / N), CD_THREADS, 0, st>>>((const T*)x, (const T*)dy, w, (T*)dx,
+                                                                               partials, n_pix, Cin, ppb);
+  else
+    conv1x1_bwd_kernel<T, 1, CO><<<dim3(nblk, Cin), CD_THREADS, 0, st>>>((const T*)x, (const T*)dy, w, (T*)dx,
+                                                                          partials, n_pix, Cin, ppb);
+  launch_reduce_partials(partials, nblk, CO * Cin, dw, st, CO * Cin + CO);
+  launch_reduce_partials(partials + CO * Cin, nblk, CO, dbias, st, CO * Cin + CO);
+  return 0;
+}
+
+#define DISPATCH_CO(FN, T, CO, ...)               \
+  switch (CO) {                                   \
+    case 1: FN<T, 1>(__VA_ARGS__); break;         \
+    case 2: FN<T, 2>(__VA_ARGS__); break;         \
+    case 3: FN<T, 3>(__VA_ARGS__); break;         \
+    case 4: FN<T, 4>(__VA_ARGS__); break;         \
+    case 5: FN<T, 5>(__VA_ARGS__); break;         \
+    case 6: FN<T, 6>(__VA_ARGS__); break;         \
+    case 7: FN<T, 7>(__VA_ARGS__); break;         \
+    case 8: FN<T, 8>(__VA_ARGS__); break;         \
+    case 9: FN<T, 9>(__VA_ARGS__); break;         \
+    case 10: FN<T, 10>(__VA_ARGS__); break;       \
+    case 11: FN<T, 11>(__VA_ARGS__); break;       \
+    case 12: FN<T, 12>(__VA_ARGS__); break;       \
+    case 13: FN<T, 13>(__VA_ARGS__); break;       \
+    case 14: FN<T, 14>(__VA_ARGS__); break;       \
+    case 15: FN<T, 15>(__VA_ARGS__); break;       \
+    case 16: FN<T, 16>(__VA_ARGS__); break;       \
+  }
+
+}  // namespace
+
+// Entry points shared with the MFMA file (declared in conv_internal.h).
+#include "conv_internal.h"
+
+size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout) {
+  return align256((size_t)cdiv(n_pix, CD_THREADS) * 2 * Cout * sizeof(float));
+}
+
+int conv3x3_direct_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
+                       int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
+  const int64_t n_pix = (int64_t)B * H * W;
+  dim3 grid(cdiv(n_pix, CD_THREADS), cdiv(Cout, CO_T));
+  float* partials = stats ? (float*)workspace : nullptr;
+  if (dtype == MIS_F32) {
+    if (Cin % 4 == 0 && ((uintptr_t)x % 16) == 0)
+      conv3x3_direct_kernel<float, 4><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)wp, bias, (float*)z,
+                                                                    partials, B, H, W, Cin, Cout);
+    else
+      conv3x3_direct_kernel<float, 1><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)wp, bias, (float*)z,
+                                                                    partials, B, H, W, Cin, Cout);
+  } else {
+    if (Cin % 8 == 0 && ((uintptr_t)x % 16) == 0)
+      conv3x3_direct_kernel<bf16, 8><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)wp, bias, (bf16*)z,
+                                                                   partials, B, H, W, Cin, Cout);
+    else
+      conv3x3_direct_kernel<bf16, 1><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)wp, bias, (bf16*)z,
+                                                                   partials, B, H, W, Cin, Cout);
+  }
+  MIS_CHECK_LAUNCH("conv3x3_direct_kernel");
+  if (stats) {
+    launch_reduce_partials(partials, grid.x, 2 * Cout, stats, st);
+    MIS_CHECK_LAUNCH("reduce_partials_kernel");
+  }
+  return MIS_OK;
+}
+
+int conv3x3_direct_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
+                         hipStream_t st) {
+  const int64_t n_pix = (int64_t)B * H * W;
+  if (hipMemsetAsync(dw, 0, (size_t)Cout * Cin * 9 * sizeof(float), st) != hipSuccess) {
+    mis_set_error("conv3x3_wgrad: memset failed");
+    return MIS_ERR_LAUNCH;
+  }
+  int nblk = (int)((n_pix + CD_THREADS * 16 - 1) / (CD_THREADS * 16));
+  const int per = cdiv(Cout, CO_T) * Cin;
+  const int cap = per >= 2048 ? 1 : 2048 / per;
+  if (nblk > cap) nblk = cap;
+  if (nblk < 1) nblk = 1;
+  const int64_t ppb = (n_pix + nblk - 1) / nblk;
+  dim3 grid(nblk, cdiv(Cout, CO_T), Cin);
+  if (dtype == MIS_F32)
+    conv3x3_wgrad_direct_kernel<float><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)dz, dw, B, H, W, Cin,
+                                                                     Cout, ppb);
+  else
+    conv3x3_wgrad_direct_kernel<bf16><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)dz, dw, B, H, W, Cin,
+                                                                    Cout, ppb);
+  MIS_CHECK_LAUNCH("conv3x3_wgrad_direct_kernel");
+  return MIS_OK;
+}
+
+extern "C" {
+
+int mis_pack_conv3x3_weights(const float* w, int Cout, int Cin, int dtype, void* w_fwd, void* w_dgrad,
+                             mis_stream_t stream) {
+  MIS_REQUIRE(w && (w_fwd || w_dgrad) && Cout >= 1 && Cin >= 1, "pack_conv3x3_weights: bad arguments");
+  const int64_t n = (int64_t)Cout * Cin * 9;
+  const int grid = ew_grid(n, 256);
+  if (dtype == MIS_F32)
+    pack_w3x3_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, (float*)w_fwd, (float*)w_dgrad);
+  else if (dtype == MIS_BF16)
+    pack_w3x3_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, (bf16*)w_fwd, (bf16*)w_dgrad);
+  else MIS_REQUIRE(false, "pack_conv3x3_weights: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("pack_w3x3_kernel");
+  return MIS_OK;
+}
+
+int mis_conv1x1_fwd(const void* x, int dtype, int64_t n_pix, int Cin, int Cout, const float* w, const float* bias,
+                    void* y, mis_stream_t stream) {
+  MIS_REQUIRE(x && w && y && n_pix >= 1 && Cin >= 1, "conv1x1_fwd: bad arguments");
+  MIS_REQUIRE(Cout >= 1 && Cout <= 16, "conv1x1_fwd: 1 <= Cout <= 16 required (got %d)", Cout);
+  MIS_REQUIRE((size_t)Cin * Cout * 4 <= 48 * 1024, "conv1x1_fwd: Cin*Cout too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIS_F32) { DISPATCH_CO(conv1x1_fwd_t, float, Cout, x, n_pix, Cin, w, bias, y, st) }
+  else if (dtype == MIS_BF16) { DISPATCH_CO(conv1x1_fwd_t, bf16, Cout, x, n_pix, Cin, w, bias, y, st) }
+  else MIS_REQUIRE(false, "conv1x1_fwd: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("conv1x1_fwd_kernel");
+  return MIS_OK;
+}
+
+size_t mis_conv1x1_bwd_workspace_bytes(int64_t n_pix, int Cin, int Cout) {
+  return align256((size_t)C1_MAX_BLOCKS * ((size_t)Cout * Cin + Cout) * sizeof(float));
+}
+
+int mis_conv1x1_bwd(const void* x, const void* dy, int dtype, int64_t n_pix, int Cin, int Cout, const float* w,
+                    void* dx, float* dw, float* dbias, void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(x && dy && w && dw && dbias && workspace && n_pix >= 1 && Cin >= 1, "conv1x1_bwd: bad arguments");
+  MIS_REQUIRE(Cout >= 1 && Cout <= 16, "conv1x1_bwd: 1 <= Cout <= 16 required (got %d)", Cout);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIS_F32) { DISPATCH_CO(conv1x1_bwd_t, float, Cout, x, dy, n_pix, Cin, w, dx, dw, dbias, workspace, st) }
+  else if (dtype == MIS_BF16) { DISPATCH_CO(conv1x1_bwd_t, bf16, Cout, x, dy, n_pix, Cin, w, dx, dw, dbias, workspace, st) }
+  else MIS_REQUIRE(false, "conv1x1_bwd: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("conv1x1_bwd_kernel");
+  return MIS_OK;
+}
+
+int mis_nchw_f32_to_nhwc(const float* x, int B, int C, int H, int W, int dtype, void* y, mis_stream_t stream) {
+  MIS_REQUIRE(x && y && B >= 1 && C >= 1 && H >= 1 && W >= 1, "nchw_f32_to_nhwc: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  const int grid = ew_grid((int64_t)B * HW, 256);
+  if (dtype == MIS_F32) nchw_to_nhwc_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(x, (float*)y, B, C, HW);
+  else if (dtype == MIS_BF16) nchw_to_nhwc_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(x, (bf16*)y, B, C, HW);
+  else MIS_REQUIRE(false, "nchw_f32_to_nhwc: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+  return MIS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,19 @@
+// Internal (non-exported) conv entry points shared between translation units.
+#pragma once
+#include "common.h"
+
+size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout);
+int conv3x3_direct_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
+                       int Cout, void* z, float* stats, void* workspace, hipStream_t st);
+int conv3x3_direct_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
+                         hipStream_t st);
+
+// Matrix-core path (conv_mfma.hip).  *_supported tell whether the shape is taken.
+bool conv3x3_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
+size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
+int conv3x3_mfma_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
+                     int Cout, void* z, float* stats, void* workspace, hipStream_t st);
+bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
+size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
+int conv3x3_wgrad_mfma(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
+                       void* workspace, hipStream_t st);

@@ -1,0 +1,323 @@
+// Down (2x2 max-pool) and Up (bilinear x2, align_corners=True, + skip concat) on
+// channels-last tensors.  All four kernels are pure streaming: one lane moves a
+// 16-byte channel vector, consecutive lanes take consecutive channel vectors of a
+// pixel and then the next pixel, so every wave access is a contiguous 1 KiB.
+//
+// Roofline: HBM.  Algorithmic bytes (elements * sizeof(T)):
+//   pool fwd   : read 4*n_out*C, write n_out*C
+//   pool bwd   : read 4*n_out*C (x) + n_out*C (dy), write 4*n_out*C
+//   up+cat fwd : read n_low*Cup + 4*n_low*Cskip, write 4*n_low*(Cup+Cskip)
+//   up+cat bwd : read 4*n_low*(Cup+Cskip), write n_low*Cup + 4*n_low*Cskip
+#include "common.h"
+#include "vec.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+template <typename T, int V>
+__global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                 int B, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / V;
+  const int64_t total = (int64_t)B * Ho * Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const T* src = x + (((int64_t)b * H + 2 * yo) * W + 2 * xo) * C + cv * V;
+    float v00[V], v01[V], v10[V], v11[V], m[V];
+    vload<T, V>(src, v00);
+    vload<T, V>(src + C, v01);
+    vload<T, V>(src + (int64_t)W * C, v10);
+    vload<T, V>(src + (int64_t)W * C + C, v11);
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      float mm = v00[k];
+      mm = (v01[k] > mm || v01[k] != v01[k]) ? v01[k] : mm;
+      mm = (v10[k] > mm || v10[k] != v10[k]) ? v10[k] : mm;
+      mm = (v11[k] > mm || v11[k] != v11[k]) ? v11[k] : mm;
+      m[k] = mm;
+    }
+    vstore<T, V>(y + i * V, m);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                 T* __restrict__ dx, int B, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / V;
+  const int64_t total = (int64_t)B * Ho * Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const int64_t off = (((int64_t)b * H + 2 * yo) * W + 2 * xo) * C + cv * V;
+    const T* src = x + off;
+    float v[4][V], g[V], o[4][V];
+    vload<T, V>(src, v[0]);
+    vload<T, V>(src + C, v[1]);
+    vload<T, V>(src + (int64_t)W * C, v[2]);
+    vload<T, V>(src + (int64_t)W * C + C, v[3]);
+    vload<T, V>(dy + i * V, g);
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      float mm = v[0][k];
+      int am = 0;
+#pragma unroll
+      for (int j = 1; j < 4; j++) {
+        const bool take = (v[j][k] > mm) || (v[j][k] != v[j][k]);
+        mm = take ? v[j][k] : mm;
+        am = take ? j : am;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) o[j][k] = (am == j) ? g[k] : 0.f;
+    }
+    T* dst = dx + off;
+    vstore<T, V>(dst, o[0]);
+    vstore<T, V>(dst + C, o[1]);
+    vstore<T, V>(dst + (int64_t)W * C, o[2]);
+    vstore<T, V>(dst + (int64_t)W * C + C, o[3]);
+  }
+}
+
+// align_corners=True source coordinate, computed as torch does (float scale, float product).
+__device__ __forceinline__ void up_taps(int dst, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
+  const float src = scale * (float)dst;
+  i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + ((i0 < n_in - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(EW_THREADS) void upcat_fwd_kernel(const T* __restrict__ low, const T* __restrict__ skip,
+                                                               T* __restrict__ out, int B, int h, int w, int Cup,
+                                                               int Cskip, float sy, float sx) {
+  const int Ho = 2 * h, Wo = 2 * w, Ct = Cup + Cskip, CV = Ct / V, CVup = Cup / V;
+  const int64_t total = (int64_t)B * Ho * Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float r[V];
+    if (cv < CVup) {
+      int y0, y1, x0, x1;
+      float hy0, hy1, wx0, wx1;
+      up_taps(yo, sy, h, y0, y1, hy0, hy1);
+      up_taps(xo, sx, w, x0, x1, wx0, wx1);
+      const T* base = low + (int64_t)b * h * w * Cup + cv * V;
+      float a[V], bq[V], c[V], d[V];
+      vload<T, V>(base + ((int64_t)y0 * w + x0) * Cup, a);
+      vload<T, V>(base + ((int64_t)y0 * w + x1) * Cup, bq);
+      vload<T, V>(base + ((int64_t)y1 * w + x0) * Cup, c);
+      vload<T, V>(base + ((int64_t)y1 * w + x1) * Cup, d);
+#pragma unroll
+      for (int k = 0; k < V; k++) r[k] = hy0 * (wx0 * a[k] + wx1 * bq[k]) + hy1 * (wx0 * c[k] + wx1 * d[k]);
+    } else {
+      vload<T, V>(skip + (((int64_t)b * Ho + yo) * Wo + xo) * Cskip + (cv - CVup) * V, r);
+    }
+    vstore<T, V>(out + i * V, r);
+  }
+}
+
+// Gather form of the transposed interpolation: a low-res pixel collects from every
+// high-res pixel whose taps touch it (|offset| <= 4 rows/cols), with the forward's weights.
+template <typename T, int V>
+__global__ __launch_bounds__(EW_THREADS) void up_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dlow, int B,
+                                                            int h, int w, int Cup, int Ct, float sy, float sx) {
+  const int Ho = 2 * h, Wo = 2 * w, CV = Cup / V;
+  const int64_t total = (int64_t)B * h * w * CV;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int xl = (int)(p % w);
+    p /= w;
+    const int yl = (int)(p % h);
+    const int b = (int)(p / h);
+    float wy[8], wxv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int i0, i1;
+      float l0, l1;
+      const int Y = 2 * yl - 3 + k;
+      float wgt = 0.f;
+      if (Y >= 0 && Y < Ho) {
+        up_taps(Y, sy, h, i0, i1, l0, l1);
+        wgt = ((i0 == yl) ? l0 : 0.f) + ((i1 == yl) ? l1 : 0.f);
+      }
+      wy[k] = wgt;
+      const int X = 2 * xl - 3 + k;
+      wgt = 0.f;
+      if (X >= 0 && X < Wo) {
+        up_taps(X, sx, w, i0, i1, l0, l1);
+        wgt = ((i0 == xl) ? l0 : 0.f) + ((i1 == xl) ? l1 : 0.f);
+      }
+      wxv[k] = wgt;
+    }
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) acc[k] = 0.f;
+    const T* base = dout + (int64_t)b * Ho * Wo * Ct + cv * V;
+#pragma unroll
+    for (int ky = 0; ky < 8; ky++) {
+      if (wy[ky] == 0.f) continue;
+      const int Y = 2 * yl - 3 + ky;
+      float row[V];
+#pragma unroll
+      for (int k = 0; k < V; k++) row[k] = 0.f;
+#pragma unroll
+      for (int kx = 0; kx < 8; kx++) {
+        if (wxv[kx] == 0.f) continue;
+        const int X = 2 * xl - 3 + kx;
+        float g[V];
+        vload<T, V>(base + ((int64_t)Y * Wo + X) * Ct, g);
+#pragma unroll
+        for (int k = 0; k < V; k++) row[k] += wxv[kx] * g[k];
+      }
+#pragma unroll
+      for (int k = 0; k < V; k++) acc[k] += wy[ky] * row[k];
+    }
+    vstore<T, V>(dlow + i * V, acc);
+  }
+}
+
+// dskip[pix][0:Cskip] = dout[pix][Cup:Cup+Cskip]
+template <typename T, int V>
+__global__ __launch_bounds__(EW_THREADS) void slice_channels_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                                    int64_t n_pix, int Ct, int c0, int Cs) {
+  const int CV = Cs / V;
+  const int64_t total = n_pix * CV;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int cv = (int)(i % CV);
+    const int64_t p = i / CV;
+    float v[V];
+    vload<T, V>(src + p * Ct + c0 + cv * V, v);
+    vstore<T, V>(dst + i * V, v);
+  }
+}
+
+template <typename T>
+int pool_fwd(const void* x, void* y, int B, int H, int W, int C, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
+  if (pick_vec<T>(C, x, y) == N)
+    maxpool_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, 0, st>>>((const T*)x, (T*)y, B, H, W, C);
+  else
+    maxpool_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, 0, st>>>((const T*)x, (T*)y, B, H, W, C);
+  return 0;
+}
+
+template <typename T>
+int pool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
+  if (pick_vec<T>(C, x, dy, dx) == N)
+    maxpool_bwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, 0, st>>>((const T*)x, (const T*)dy, (T*)dx, B,
+                                                                                  H, W, C);
+  else
+    maxpool_bwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, 0, st>>>((const T*)x, (const T*)dy, (T*)dx, B, H,
+                                                                              W, C);
+  return 0;
+}
+
+inline float up_scale(int n_in) { return (2 * n_in > 1) ? (float)(n_in - 1) / (float)(2 * n_in - 1) : 0.f; }
+
+template <typename T>
+int upcat_fwd(const void* low, const void* skip, void* out, int B, int h, int w, int Cup, int Cskip, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  const int Ct = Cup + Cskip;
+  const int64_t n = (int64_t)B * 4 * h * w * Ct;
+  const bool vec = (Cup % N == 0) && (Cskip % N == 0) && pick_vec<T>(Ct, low, skip, out) == N;
+  if (vec)
+    upcat_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, 0, st>>>((const T*)low, (const T*)skip, (T*)out,
+                                                                                B, h, w, Cup, Cskip, up_scale(h),
+                                                                                up_scale(w));
+  else
+    upcat_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, 0, st>>>((const T*)low, (const T*)skip, (T*)out, B,
+                                                                            h, w, Cup, Cskip, up_scale(h), up_scale(w));
+  return 0;
+}
+
+template <typename T>
+int upcat_bwd(const void* dout, void* dlow, void* dskip, int B, int h, int w, int Cup, int Cskip, hipStream_t st) {
+  constexpr int N = VecOf<T>::N;
+  const int Ct = Cup + Cskip;
+  const bool vec = (Cup % N == 0) && (Cskip % N == 0) && pick_vec<T>(Ct, dout, dlow, dskip) == N;
+  const int64_t nl = (int64_t)B * h * w * Cup;
+  const int64_t npix = (int64_t)B * 4 * h * w;
+  if (vec) {
+    up_bwd_kernel<T, N><<<ew_grid(nl / N, EW_THREADS), EW_THREADS, 0, st>>>((const T*)dout, (T*)dlow, B, h, w, Cup, Ct,
+                                                                              up_scale(h), up_scale(w));
+    if (dskip && Cskip > 0)
+      slice_channels_kernel<T, N><<<ew_grid(npix * Cskip / N, EW_THREADS), EW_THREADS, 0, st>>>(
+          (const T*)dout, (T*)dskip, npix, Ct, Cup, Cskip);
+  } else {
+    up_bwd_kernel<T, 1><<<ew_grid(nl, EW_THREADS), EW_THREADS, 0, st>>>((const T*)dout, (T*)dlow, B, h, w, Cup, Ct,
+                                                                          up_scale(h), up_scale(w));
+    if (dskip && Cskip > 0)
+      slice_channels_kernel<T, 1><<<ew_grid(npix * Cskip, EW_THREADS), EW_THREADS, 0, st>>>(
+          (const T*)dout, (T*)dskip, npix, Ct, Cup, Cskip);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mis_maxpool2x2_fwd(const void* x, int dtype, int B, int H, int W, int C, void* y, mis_stream_t stream) {
+  MIS_REQUIRE(x && y, "maxpool2x2_fwd: null pointer");
+  MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+              "maxpool2x2_fwd: H and W must be even and >= 2 (got %dx%d)", H, W);
+  if (dtype == MIS_F32) pool_fwd<float>(x, y, B, H, W, C, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) pool_fwd<bf16>(x, y, B, H, W, C, (hipStream_t)stream);
+  else MIS_REQUIRE(false, "maxpool2x2_fwd: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("maxpool_fwd_kernel");
+  return MIS_OK;
+}
+
+int mis_maxpool2x2_bwd(const void* x, const void* dy, int dtype, int B, int H, int W, int C, void* dx,
+                       mis_stream_t stream) {
+  MIS_REQUIRE(x && dy && dx, "maxpool2x2_bwd: null pointer");
+  MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+              "maxpool2x2_bwd: H and W must be even and >= 2 (got %dx%d)", H, W);
+  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx, B, H, W, C, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx, B, H, W, C, (hipStream_t)stream);
+  else MIS_REQUIRE(false, "maxpool2x2_bwd: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("maxpool_bwd_kernel");
+  return MIS_OK;
+}
+
+int mis_upsample2x_cat_fwd(const void* low, const void* skip, int dtype, int B, int h, int w, int Cup, int Cskip,
+                           void* out, mis_stream_t stream) {
+  MIS_REQUIRE(low && out && (skip || Cskip == 0), "upsample2x_cat_fwd: null pointer");
+  MIS_REQUIRE(B >= 1 && h >= 1 && w >= 1 && Cup >= 1 && Cskip >= 0, "upsample2x_cat_fwd: bad shape");
+  if (dtype == MIS_F32) upcat_fwd<float>(low, skip, out, B, h, w, Cup, Cskip, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) upcat_fwd<bf16>(low, skip, out, B, h, w, Cup, Cskip, (hipStream_t)stream);
+  else MIS_REQUIRE(false, "upsample2x_cat_fwd: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("upcat_fwd_kernel");
+  return MIS_OK;
+}
+
+int mis_upsample2x_cat_bwd(const void* dout, int dtype, int B, int h, int w, int Cup, int Cskip, void* dlow,
+                           void* dskip, mis_stream_t stream) {
+  MIS_REQUIRE(dout && dlow && (dskip || Cskip == 0), "upsample2x_cat_bwd: null pointer");
+  MIS_REQUIRE(B >= 1 && h >= 1 && w >= 1 && Cup >= 1 && Cskip >= 0, "upsample2x_cat_bwd: bad shape");
+  if (dtype == MIS_F32) upcat_bwd<float>(dout, dlow, dskip, B, h, w, Cup, Cskip, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) upcat_bwd<bf16>(dout, dlow, dskip, B, h, w, Cup, Cskip, (hipStream_t)stream);
+  else MIS_REQUIRE(false, "upsample2x_cat_bwd: bad dtype %d", dtype);
+  MIS_CHECK_LAUNCH("up_bwd_kernel");
+  return MIS_OK;
+}
+
+}  // extern "C"

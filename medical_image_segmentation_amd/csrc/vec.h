@@ -1,0 +1,60 @@
+// 16-byte channel vectors for channels-last tensors: 8 x bf16 or 4 x float per lane.
+#pragma once
+#include "common.h"
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<bf16> { static constexpr int N = 8; };
+
+// Loads N consecutive elements (N*sizeof(T) == 16 -> one dwordx4) into floats.
+template <typename T, int N>
+__device__ __forceinline__ void vload(const T* __restrict__ p, float (&v)[N]) {
+  if constexpr (N * sizeof(T) == 16) {
+    union { uint4 u; T t[N]; } r;
+    r.u = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = to_f32(r.t[i]);
+  } else if constexpr (N * sizeof(T) == 8) {
+    union { uint2 u; T t[N]; } r;
+    r.u = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = to_f32(r.t[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = to_f32(p[i]);
+  }
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void vstore(T* __restrict__ p, const float (&v)[N]) {
+  if constexpr (N * sizeof(T) == 16) {
+    union { uint4 u; T t[N]; } r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.t[i] = from_f32<T>(v[i]);
+    *reinterpret_cast<uint4*>(p) = r.u;
+  } else if constexpr (N * sizeof(T) == 8) {
+    union { uint2 u; T t[N]; } r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.t[i] = from_f32<T>(v[i]);
+    *reinterpret_cast<uint2*>(p) = r.u;
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) p[i] = from_f32<T>(v[i]);
+  }
+}
+
+// Picks the widest channel vector (full 16 B, else scalar) that divides C and keeps alignment.
+template <typename T>
+static inline int pick_vec(int C, const void* a, const void* b = nullptr, const void* c = nullptr,
+                           const void* d = nullptr) {
+  const int n = VecOf<T>::N;
+  const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d;
+  return (C % n == 0 && (m % 16) == 0) ? n : 1;
+}
+
+static inline int ew_grid(int64_t work_items, int threads) {
+  int64_t g = (work_items + threads - 1) / threads;
+  if (g > 256 * 16) g = 256 * 16;   // grid-stride beyond ~16 blocks per CU
+  if (g < 1) g = 1;
+  return (int)g;
+}

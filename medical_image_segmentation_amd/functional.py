@@ -1,0 +1,343 @@
+"""Tensor-level wrappers and autograd Functions over the C-ABI (include/misamd.h).
+
+PyTorch is used for device memory, streams and the autograd graph only: every op
+below launches hand-written gfx950 kernels through `_lib.call`, on torch's current
+stream, on tensors owned by torch's caching allocator.
+
+Layout contract: an activation is a torch tensor of logical shape [B, C, H, W]
+stored channels-last (`memory_format=torch.channels_last`), dtype float32 or
+bfloat16.  Parameters are float32 in the reference's own layouts.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, query
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported activation dtype {t.dtype}: use float32 or bfloat16") from None
+
+
+def _check_act(t, name="x"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the MI355X kernels need a CUDA/HIP tensor, got {t.device} "
+                           "(there is no CPU fallback)")
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected [B, C, H, W], got {tuple(t.shape)}")
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError(f"{name}: activation must be channels-last")
+    return t
+
+
+def to_act(t, dtype=None):
+    """Any [B,C,H,W] tensor -> channels-last activation of `dtype` (default: keep)."""
+    dtype = dtype or t.dtype
+    if t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda and dtype in _DT and t.shape[1] > 1:
+        B, Cc, H, W = t.shape
+        y = torch.empty((B, Cc, H, W), dtype=dtype, device=t.device, memory_format=torch.channels_last)
+        call("mis_nchw_f32_to_nhwc", t.data_ptr(), B, Cc, H, W, _DT[dtype], y.data_ptr(), _stream())
+        return y
+    return t.to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+def _empty_act(B, Cc, H, W, like):
+    return torch.empty((B, Cc, H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """One growing scratch buffer per device.  Every kernel that uses it runs on the
+    current stream, so consecutive users are ordered by the stream itself."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------
+# raw ops (no autograd)
+# ---------------------------------------------------------------------------
+def pack_weights(w, dtype, fwd=True, dgrad=False):
+    Co, Ci = w.shape[0], w.shape[1]
+    wf = torch.empty((9, Co, Ci), dtype=dtype, device=w.device) if fwd else None
+    wd = torch.empty((9, Ci, Co), dtype=dtype, device=w.device) if dgrad else None
+    call("mis_pack_conv3x3_weights", w.data_ptr(), Co, Ci, _DT[dtype],
+         wf.data_ptr() if fwd else None, wd.data_ptr() if dgrad else None, _stream())
+    return wf, wd
+
+
+def conv3x3_raw(x, w_packed, bias, Cout, want_stats):
+    """z = conv3x3(x) + bias; optionally the per-channel (sum, sumsq) of z."""
+    B, Cin, H, W = x.shape
+    z = _empty_act(B, Cout, H, W, x)
+    stats = torch.empty((2, Cout), dtype=torch.float32, device=x.device) if want_stats else None
+    ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Cout), x.device)
+    call("mis_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+         _dt(x), B, H, W, Cin, Cout, z.data_ptr(), stats.data_ptr() if want_stats else None, ws.data_ptr(),
+         _stream())
+    return z, stats
+
+
+def conv3x3_wgrad_raw(x, dz):
+    B, Cin, H, W = x.shape
+    Cout = dz.shape[1]
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    ws = workspace(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), x.device)
+    call("mis_conv3x3_wgrad", x.data_ptr(), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout, dw.data_ptr(),
+         ws.data_ptr(), _stream())
+    return dw
+
+
+def channel_sum_raw(x):
+    B, Cc, H, W = x.shape
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = workspace(query("mis_channel_sum_workspace_bytes", B * H * W, Cc), x.device)
+    call("mis_channel_sum", x.data_ptr(), _dt(x), B * H * W, Cc, out.data_ptr(), ws.data_ptr(), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Conv3x3 + BatchNorm2d + ReLU   (model/utils/modules.py:86-94)
+# ---------------------------------------------------------------------------
+class ConvBnReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps, momentum):
+        _check_act(x)
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        if weight.shape != (Cout, Cin, 3, 3):
+            raise ValueError(f"weight {tuple(weight.shape)} does not match input channels {Cin}")
+        n_pix = B * H * W
+        wf, _ = pack_weights(weight.detach(), x.dtype, fwd=True)
+        z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout, training)
+        ss = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+        mr = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+        st = _stream()
+        if training:
+            if n_pix <= 1:
+                raise ValueError("Expected more than 1 value per channel when training")
+            call("mis_bn_finalize", stats.data_ptr(), Cout, n_pix, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                 running_mean.data_ptr() if running_mean is not None else None,
+                 running_var.data_ptr() if running_var is not None else None,
+                 nbt.data_ptr() if nbt is not None else None, ss.data_ptr(), mr.data_ptr(), st)
+        else:
+            call("mis_bn_eval_affine", running_mean.data_ptr(), running_var.data_ptr(), gamma.data_ptr(),
+                 beta.data_ptr(), Cout, eps, ss.data_ptr(), st)
+            mr[0].copy_(running_mean)
+            mr[1].copy_(torch.rsqrt(running_var + eps))
+        a = _empty_act(B, Cout, H, W, x)
+        call("mis_bn_relu_apply", z.data_ptr(), _dt(x), n_pix, Cout, ss.data_ptr(), a.data_ptr(), st)
+        ctx.save_for_backward(x, z, weight, gamma, beta, mr)
+        ctx.training = training
+        ctx.has_bias = bias is not None
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, z, weight, gamma, beta, mr = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        n_pix = B * H * W
+        da = to_act(da, x.dtype)
+        st = _stream()
+        sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+        ws = workspace(query("mis_bn_relu_bwd_workspace_bytes", n_pix, Cout), x.device)
+        call("mis_bn_relu_bwd_reduce", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
+             gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ws.data_ptr(), st)
+        dgamma, dbeta = sums[1].clone(), sums[0].clone()
+        # eval mode: statistics are constants, so the two projection terms vanish
+        proj = sums if ctx.training else torch.zeros_like(sums)
+        dz = torch.empty_like(z)
+        call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
+             gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(), st)
+        dbias = channel_sum_raw(dz) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, wd = pack_weights(weight.detach(), x.dtype, fwd=False, dgrad=True)
+            dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
+        dw = conv3x3_wgrad_raw(x, dz) if ctx.needs_input_grad[1] else None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
+
+
+def conv_bn_relu(x, conv, bn, training):
+    """x -> relu(bn(conv(x))) with the parameters of an nn.Conv2d / nn.BatchNorm2d pair."""
+    momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
+    return ConvBnReluFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                              bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum))
+
+
+# ---------------------------------------------------------------------------
+# Down / Up   (model/unet.py:19-20, 48-81)
+# ---------------------------------------------------------------------------
+class MaxPool2x2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check_act(x)
+        B, Cc, H, W = x.shape
+        if H % 2 or W % 2:
+            raise ValueError(f"max-pool 2x2 needs even H and W, got {H}x{W}")
+        y = _empty_act(B, Cc, H // 2, W // 2, x)
+        call("mis_maxpool2x2_fwd", x.data_ptr(), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        dy = to_act(dy, x.dtype)
+        dx = torch.empty_like(x)
+        call("mis_maxpool2x2_bwd", x.data_ptr(), dy.data_ptr(), _dt(x), B, H, W, Cc, dx.data_ptr(), _stream())
+        return dx
+
+
+class UpsampleCatFn(torch.autograd.Function):
+    """cat([bilinear_x2(low), skip], dim=1) — upsampled channels first (unet.py:66-67)."""
+
+    @staticmethod
+    def forward(ctx, low, skip):
+        _check_act(low, "low")
+        _check_act(skip, "skip")
+        B, Cup, h, w = low.shape
+        Bs, Cskip, Hs, Ws = skip.shape
+        if (Bs, Hs, Ws) != (B, 2 * h, 2 * w) or skip.dtype != low.dtype:
+            raise ValueError(f"skip {tuple(skip.shape)} does not match upsampled {(B, Cup, 2 * h, 2 * w)}")
+        out = _empty_act(B, Cup + Cskip, 2 * h, 2 * w, low)
+        call("mis_upsample2x_cat_fwd", low.data_ptr(), skip.data_ptr(), _dt(low), B, h, w, Cup, Cskip,
+             out.data_ptr(), _stream())
+        ctx.dims = (B, h, w, Cup, Cskip)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, h, w, Cup, Cskip = ctx.dims
+        dout = to_act(dout)
+        dlow = _empty_act(B, Cup, h, w, dout)
+        dskip = _empty_act(B, Cskip, 2 * h, 2 * w, dout)
+        call("mis_upsample2x_cat_bwd", dout.data_ptr(), _dt(dout), B, h, w, Cup, Cskip, dlow.data_ptr(),
+             dskip.data_ptr(), _stream())
+        return dlow, dskip
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    """nn.Conv2d(Cin, n_classes, 1) — unet.py:44,84."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _check_act(x)
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = _empty_act(B, Cout, H, W, x)
+        call("mis_conv1x1_fwd", x.data_ptr(), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
+             bias.data_ptr() if bias is not None else None, y.data_ptr(), _stream())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = to_act(dy, x.dtype)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        ws = workspace(query("mis_conv1x1_bwd_workspace_bytes", B * H * W, Cin, Cout), x.device)
+        call("mis_conv1x1_bwd", x.data_ptr(), dy.data_ptr(), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
+             dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream())
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+# ---------------------------------------------------------------------------
+# loss + metrics   (utils/loss_fn.py:63-88,199-203; utils/metrics.py:24-36)
+# ---------------------------------------------------------------------------
+def _logit_strides(logits):
+    """(stride_b, stride_c, stride_p) in elements for a [B,C,H,W] tensor whose H,W are
+    jointly contiguous (NCHW-contiguous or channels-last); else a contiguous copy."""
+    B, Cc, H, W = logits.shape
+    sb, sc, sh, sw = logits.stride()
+    if sh == W * sw and (B == 1 or sb >= 0):
+        return logits, sb, sc, sw
+    logits = logits.contiguous()
+    sb, sc, sh, sw = logits.stride()
+    return logits, sb, sc, sw
+
+
+def loss_metrics_raw(logits, target, want_sums=True, want_ce=False, want_cm=True):
+    """One pass over the logits: pooled Dice sums [3,C], CE map [B,H,W], confusion
+    counts [B,C,C] (int64) and the device status word (non-zero: target out of range)."""
+    if not logits.is_cuda:
+        raise RuntimeError("loss/metrics kernels need a CUDA/HIP tensor (there is no CPU fallback)")
+    if logits.dim() != 4:
+        raise ValueError(f"logits: expected [B, C, H, W], got {tuple(logits.shape)}")
+    if logits.dtype not in _DT:
+        logits = logits.float()
+    B, Cc, H, W = logits.shape
+    if target.shape != (B, H, W):
+        raise ValueError(f"target {tuple(target.shape)} does not match logits {(B, H, W)}")
+    target = target.to(torch.int64).contiguous()
+    logits, sb, sc, sp = _logit_strides(logits)
+    dev = logits.device
+    sums = torch.empty((3, Cc), dtype=torch.float32, device=dev) if want_sums else None
+    ce = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_ce else None
+    cm = torch.empty((B, Cc, Cc), dtype=torch.int64, device=dev) if want_cm else None
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = workspace(query("mis_loss_metrics_workspace_bytes", B, Cc, H * W), dev)
+    p = lambda t: t.data_ptr() if t is not None else None
+    call("mis_loss_metrics_fwd", logits.data_ptr(), _dt(logits), sb, sc, sp, target.data_ptr(), B, Cc, H * W,
+         p(sums), p(ce), p(cm), status.data_ptr(), ws.data_ptr(), _stream())
+    return sums, ce, cm, status, logits, target
+
+
+class DiceLossFn(torch.autograd.Function):
+    """losses[C] = (per-foreground-class Dice losses..., total) and optionally the CE map."""
+
+    @staticmethod
+    def forward(ctx, logits, target, smooth, want_ce):
+        sums, ce, cm, status, lg, tg = loss_metrics_raw(logits, target, True, want_ce, True)
+        Cc = lg.shape[1]
+        losses = torch.empty(Cc, dtype=torch.float32, device=lg.device)
+        call("mis_dice_from_sums", sums.data_ptr(), Cc, smooth, losses.data_ptr(), _stream())
+        ctx.save_for_backward(lg, tg, sums)
+        ctx.smooth = smooth
+        ctx.in_dtype = logits.dtype
+        ctx.mark_non_differentiable(cm, status)
+        if ce is None:
+            ce = torch.zeros((), device=lg.device)
+            ctx.has_ce = False
+        else:
+            ctx.has_ce = True
+        return losses, ce, cm, status
+
+    @staticmethod
+    def backward(ctx, dlosses, dce, _dcm, _dstatus):
+        lg, tg, sums = ctx.saved_tensors
+        B, Cc, H, W = lg.shape
+        _, sb, sc, sp = _logit_strides(lg)
+        w = (dlosses if dlosses is not None else torch.zeros(Cc, device=lg.device)).to(torch.float32).contiguous()
+        dce_p = None
+        if ctx.has_ce and dce is not None:
+            dce = dce.to(torch.float32).contiguous()
+            dce_p = dce.data_ptr()
+        dlogits = torch.empty_like(lg)
+        call("mis_loss_bwd", lg.data_ptr(), _dt(lg), sb, sc, sp, tg.data_ptr(), B, Cc, H * W, sums.data_ptr(),
+             w.data_ptr(), ctx.smooth, dce_p, dlogits.data_ptr(), _stream())
+        if dlogits.dtype != ctx.in_dtype:
+            dlogits = dlogits.to(ctx.in_dtype)
+        return dlogits, None, None, None

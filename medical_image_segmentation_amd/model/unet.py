@@ -1,0 +1,84 @@
+"""UNet — drop-in for the reference's model/unet.py:10-94.
+
+Same constructor signature, attribute names (`dowm`, `up`, `encoder1-4`, `center_conv`,
+`decoder1-4`, `*_dropout*`, `out_conv`) and state_dict; `forward(x)` takes the same
+[B, in_channels, H, W] tensor and returns [B, n_classes, H, W] logits (stored
+channels-last).  Every layer runs hand-written gfx950 kernels.
+
+compute dtype: bfloat16 inside an autocast region (the reference trains under
+`autocast("cuda")`, train_and_eval.py:71), float32 outside one — or whatever
+`compute_dtype` pins.
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as F_
+from .utils.modules import DoubleConv
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channels, n_classes, p, base_channels=32, compute_dtype=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        self.compute_dtype = compute_dtype
+        self.dowm = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.encoder1 = DoubleConv(in_channels, base_channels)
+        self.encoder2 = DoubleConv(base_channels, base_channels * 2)
+        self.encoder3 = DoubleConv(base_channels * 2, base_channels * 4)
+        self.encoder4 = DoubleConv(base_channels * 4, base_channels * 8)
+        self.encoder_dropout1 = nn.Dropout2d(p=p * 0.3 if p != 0 else 0)
+        self.encoder_dropout2 = nn.Dropout2d(p=p * 0.5 if p != 0 else 0)
+        self.encoder_dropout3 = nn.Dropout2d(p=p * 0.7 if p != 0 else 0)
+        self.encoder_dropout4 = nn.Dropout2d(p=p * 0.9 if p != 0 else 0)
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.center_conv = DoubleConv(base_channels * 8, base_channels * 8, mid_channels=base_channels * 16)
+        self.bottleneck_dropout = nn.Dropout2d(p=p if p != 0.0 else 0.0)
+        self.decoder1 = DoubleConv(base_channels * 16, base_channels * 4)
+        self.decoder2 = DoubleConv(base_channels * 8, base_channels * 2)
+        self.decoder3 = DoubleConv(base_channels * 4, base_channels)
+        self.decoder4 = DoubleConv(base_channels * 2, base_channels)
+        self.decoder_dropout1 = nn.Dropout2d(p=p * 0.3 if p != 0 else 0)
+        self.decoder_dropout2 = nn.Dropout2d(p=p * 0.2 if p != 0 else 0)
+        self.out_conv = nn.Conv2d(base_channels, n_classes, kernel_size=1)
+
+    def _dtype(self):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+    @staticmethod
+    def _drop(layer, x):
+        # Dropout2d draws one Bernoulli per (sample, channel); with p == 0 (every parity
+        # configuration, predict.py:185) it is the identity and no kernel runs.
+        if layer.p == 0 or not layer.training:
+            return x
+        return layer(x)
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected [B, {self.in_channels}, H, W], got {tuple(x.shape)}")
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
+        down, upcat = F_.MaxPool2x2Fn.apply, F_.UpsampleCatFn.apply
+        x = F_.to_act(x, self._dtype())
+        x1 = self.encoder1(x)
+        x2 = self.encoder2(self._drop(self.encoder_dropout1, down(x1)))
+        x3 = self.encoder3(self._drop(self.encoder_dropout2, down(x2)))
+        x4 = self.encoder4(self._drop(self.encoder_dropout3, down(x3)))
+        x5 = self._drop(self.encoder_dropout4, down(x4))
+        y = self._drop(self.bottleneck_dropout, self.center_conv(x5))
+        y = self._drop(self.decoder_dropout1, self.decoder1(upcat(y, x4)))
+        y = self._drop(self.decoder_dropout2, self.decoder2(upcat(y, x3)))
+        y = self.decoder3(upcat(y, x2))
+        y = self.decoder4(upcat(y, x1))
+        return F_.Conv1x1Fn.apply(y, self.out_conv.weight, self.out_conv.bias)
+
+    def elastic_net(self, l1_lambda, l2_lambda):
+        l1_loss = 0
+        l2_loss = 0
+        for param in self.parameters():
+            l1_loss += torch.abs(param).sum()
+            l2_loss += torch.pow(param, 2).sum()
+        return l1_lambda * l1_loss + l2_lambda * l2_loss

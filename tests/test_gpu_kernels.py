@@ -1,0 +1,351 @@
+"""GPU suite (run with -m gpu on an MI355X): every HIP entry point, called through the
+C-ABI (ctypes), against the CPU oracle on the same seeded inputs and against the golden
+vectors generated from the reference.
+
+Tolerances: integer outputs (confusion counts, metric matrices) are compared bit-exactly;
+float32 mode at 1e-5 relative to the tensor's scale (a few 1e-5 for long reductions);
+bfloat16 mode at 1e-2 relative, the bound the task states for bf16.
+"""
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from oracle import datagen as dg
+from oracle import unet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def F_():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU suite needs a HIP device")
+    from medical_image_segmentation_amd import _lib, functional
+    _lib.load()        # fails loudly if libmisamd.so is missing
+    return functional
+
+
+def act(a, dtype=torch.float32):
+    """numpy/torch NCHW -> channels-last device activation."""
+    t = a if torch.is_tensor(a) else T(a)
+    return t.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else T(np.asarray(b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def q(a, dtype):
+    """Round test inputs to the compute dtype so both sides see identical values."""
+    t = a if torch.is_tensor(a) else T(a)
+    return t.to(dtype).to(torch.float32)
+
+
+# ---------------------------------------------------------------------------
+# loss + metrics
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(mg.loss_cases()))
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_dice_ce_vs_oracle_and_golden(F_, golden, name, dtype, layout):
+    g = golden("loss")
+    c = mg.loss_cases()[name]
+    x, t = mg.loss_inputs(c)
+    xq = q(x, dtype)
+    names = [f"c{i}" for i in range(1, c["C"])]
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss, ce_map
+    xd = xq.to(DEV).to(dtype)
+    if layout == "nhwc":
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    xd.requires_grad_(True)
+    td = T(t).to(DEV)
+    ld = diceloss(names)(xd, td)
+    assert list(ld.keys()) == names + ["total_loss"]
+    ld["total_loss"].backward()
+    xo = xq.clone().double().requires_grad_(True)
+    lo = orc.dice_loss(xo, T(t), names)
+    lo["total_loss"].backward()
+    got = np.array([float(v) for v in ld.values()])
+    np.testing.assert_allclose(got, [float(v) for v in lo.values()], rtol=2e-6, atol=2e-6)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(got, g[f"{name}.dice"], rtol=1e-5, atol=1e-6)
+        assert rel_err(xd.grad, g[f"{name}.dice_dlogits"]) < 2e-5
+    assert rel_err(xd.grad, xo.grad) < TOL[dtype]
+    ce = ce_map(xd.detach(), td)
+    assert rel_err(ce, orc.ce_map(xq.double(), T(t))) < 1e-5
+    if dtype == torch.float32:
+        assert rel_err(ce, g[f"{name}.ce_map"]) < 1e-5
+
+
+def test_ce_gradient(F_):
+    c = mg.loss_cases()["loss_c4"]
+    x, t = mg.loss_inputs(c)
+    from medical_image_segmentation_amd.utils.loss_fn import DiceCELoss
+    xd = T(x).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ld = DiceCELoss(["a", "b", "c"], ce_weight=0.7)(xd, T(t).to(DEV))
+    ld["total_loss"].backward()
+    xo = T(x).double().requires_grad_(True)
+    ref = orc.dice_loss(xo, T(t), ["a", "b", "c"])["total_loss"] + 0.7 * orc.ce_map(xo, T(t)).mean()
+    ref.backward()
+    assert abs(float(ld["total_loss"]) - float(ref)) < 1e-5
+    assert rel_err(xd.grad, xo.grad) < 2e-5
+
+
+@pytest.mark.parametrize("name", list(mg.metric_cases()))
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_metrics_bit_exact(F_, golden, name, dtype):
+    g = golden("metrics")
+    c = mg.metric_cases()[name]
+    x, t = mg.metric_inputs(c)
+    from medical_image_segmentation_amd.utils.metrics import Metrics
+    names = [f"c{i}" for i in range(1, c["n"] + 1)]
+    M = Metrics(names)
+    xd = T(x).to(DEV).to(dtype)
+    td = T(t).to(DEV)
+    cm, status = M.confusion_counts(xd, td)
+    assert int(status.item()) == 0
+    cm_ref = orc.confusion_counts(xd.float().cpu(), T(t))       # same (possibly bf16-rounded) logits
+    assert np.array_equal(cm.cpu().numpy(), cm_ref)
+    m = M.update(xd, td)
+    assert m.dtype == np.float64 and m.shape == (6, c["n"] + 1)
+    assert np.array_equal(m, orc.metrics_from_counts(cm_ref, c["n"]))
+    if dtype == torch.float32:
+        tp, fn, fp, tn = orc._counts_to_onehot_terms(cm.cpu().numpy(), c["n"] + 1)
+        for a, k in ((tp, "TP"), (fn, "FN"), (fp, "FP"), (tn, "TN")):
+            assert np.array_equal(a, g[f"{name}.{k}"])
+        assert np.array_equal(m, g[f"{name}.matrix"])
+    # channels-last logits give the same counts
+    cm2, _ = M.confusion_counts(xd.contiguous(memory_format=torch.channels_last), td)
+    assert torch.equal(cm, cm2)
+
+
+def test_metrics_reuse_counts_from_loss(F_):
+    c = mg.metric_cases()["met_n3"]
+    x, t = mg.metric_inputs(c)
+    from medical_image_segmentation_amd.utils.metrics import Metrics
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    xd, td = T(x).to(DEV), T(t).to(DEV)
+    diceloss(["a", "b", "c"])(xd, td)
+    assert getattr(xd, "_mis_counts")[0] is td
+    m1 = Metrics(["a", "b", "c"]).update(xd, td)
+    m2 = Metrics(["a", "b", "c"]).update(xd.clone(), td)
+    assert np.array_equal(m1, m2)
+
+
+def test_metrics_bad_target_raises(F_):
+    from medical_image_segmentation_amd.utils.metrics import Metrics
+    x = torch.zeros(1, 4, 16, 16, device=DEV)
+    t = torch.full((1, 16, 16), 7, dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError):
+        Metrics(["a", "b", "c"]).update(x, t)
+
+
+def test_loss_metrics_full_size_properties(F_):
+    """BASELINE size (16 x 4 x 512^2): counts against the oracle, sums against identities."""
+    B, C, H, W = 16, 4, 512, 512
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16)
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    sums, _, cm, status, _, _ = F_.loss_metrics_raw(xd, t.to(DEV), True, False, True)
+    cm = cm.cpu().numpy()
+    assert np.array_equal(cm, orc.confusion_counts(x.float(), t))
+    assert (cm.sum(axis=(1, 2)) == H * W).all()
+    s = sums.cpu().double().numpy()
+    assert abs(s[1].sum() - B * H * W) / (B * H * W) < 1e-6            # softmax sums to one
+    assert np.array_equal(s[2], cm.sum(axis=(0, 2)).astype(np.float64))   # T_c are exact integers
+    ref = orc.dice_sums(x.double(), t)
+    np.testing.assert_allclose(s[0][1:], ref[0].numpy(), rtol=2e-6)
+    np.testing.assert_allclose(s[1][1:], ref[1].numpy(), rtol=2e-6)
+
+
+# ---------------------------------------------------------------------------
+# pool / upsample+concat
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_maxpool_golden_and_ties(F_, golden, dtype):
+    g = golden("pool_up")
+    x = dg.hash_normalish((2, 3, 8, 12), 31)
+    x = np.maximum(x, 0)
+    x[0, 0, :4, :4] = 0.5
+    gy = dg.hash_normalish((2, 3, 4, 6), 32)
+    xd = act(x, dtype).requires_grad_(True)
+    y = F_.MaxPool2x2Fn.apply(xd)
+    y.backward(act(gy, dtype))
+    xo = q(x, dtype).requires_grad_(True)
+    yo = orc.maxpool2x2(xo)
+    yo.backward(q(gy, dtype))
+    assert torch.equal(y.float().cpu(), yo.detach())
+    assert torch.equal(xd.grad.float().cpu(), xo.grad)
+    if dtype == torch.float32:
+        assert np.array_equal(y.detach().cpu().numpy(), g["pool.y"])
+        assert np.array_equal(xd.grad.cpu().numpy(), g["pool.dx"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 8, 16, 24), (1, 32, 64, 64), (3, 5, 6, 10)])
+def test_maxpool_random(F_, dtype, shape):
+    x = np.maximum(dg.hash_normalish(shape, 301), 0)      # post-ReLU: many exact-zero ties
+    gy = dg.hash_normalish((shape[0], shape[1], shape[2] // 2, shape[3] // 2), 302)
+    xd = act(x, dtype).requires_grad_(True)
+    y = F_.MaxPool2x2Fn.apply(xd)
+    y.backward(act(gy, dtype))
+    xo = q(x, dtype).requires_grad_(True)
+    yo = orc.maxpool2x2(xo)
+    yo.backward(q(gy, dtype))
+    assert torch.equal(y.float().cpu(), yo.detach())
+    assert torch.equal(xd.grad.float().cpu(), xo.grad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_upsample_cat_golden(F_, golden, dtype):
+    g = golden("pool_up")
+    for name, (h, w) in {"up_2": (2, 2), "up_5": (5, 5), "up_3x7": (3, 7)}.items():
+        x = dg.hash_normalish((2, 3, h, w), 33 + h)
+        skip = dg.hash_normalish((2, 2, 2 * h, 2 * w), 43 + h)
+        gy = dg.hash_normalish((2, 5, 2 * h, 2 * w), 53 + h)
+        xd, sd = act(x, dtype).requires_grad_(True), act(skip, dtype).requires_grad_(True)
+        y = F_.UpsampleCatFn.apply(xd, sd)
+        y.backward(act(gy, dtype))
+        tol = TOL[dtype]
+        if dtype == torch.float32:
+            assert rel_err(y, g[f"{name}.y"]) < tol
+            assert rel_err(xd.grad, g[f"{name}.dx"]) < tol
+            assert np.array_equal(sd.grad.cpu().numpy(), g[f"{name}.dskip"])
+        xo, so = q(x, dtype).requires_grad_(True), q(skip, dtype).requires_grad_(True)
+        yo = torch.cat([orc.upsample2x_bilinear(xo), so], dim=1)
+        yo.backward(q(gy, dtype))
+        assert rel_err(y, yo) < tol and rel_err(xd.grad, xo.grad) < tol
+        assert torch.equal(sd.grad.float().cpu(), so.grad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 8, 8, 8), (1, 64, 16, 16, 32), (2, 8, 4, 6, 24)])
+def test_upsample_cat_random(F_, dtype, shape):
+    B, Cup, h, w, Cs = shape
+    x = dg.hash_normalish((B, Cup, h, w), 401)
+    skip = dg.hash_normalish((B, Cs, 2 * h, 2 * w), 402)
+    gy = dg.hash_normalish((B, Cup + Cs, 2 * h, 2 * w), 403)
+    xd, sd = act(x, dtype).requires_grad_(True), act(skip, dtype).requires_grad_(True)
+    y = F_.UpsampleCatFn.apply(xd, sd)
+    y.backward(act(gy, dtype))
+    xo, so = q(x, dtype).requires_grad_(True), q(skip, dtype).requires_grad_(True)
+    yo = torch.cat([orc.upsample2x_bilinear(xo), so], dim=1)
+    yo.backward(q(gy, dtype))
+    assert rel_err(y, yo) < TOL[dtype] and rel_err(xd.grad, xo.grad) < TOL[dtype]
+    assert torch.equal(sd.grad.float().cpu(), so.grad)
+
+
+# ---------------------------------------------------------------------------
+# conv + BN + ReLU, 1x1 conv
+# ---------------------------------------------------------------------------
+def _cbr_oracle(x, w, b, gam, bet, gy, dtype):
+    """float64 oracle of one conv+BN(train)+ReLU with the inputs rounded to `dtype`."""
+    xs = [q(v, dtype).double().requires_grad_(True) for v in (x, w, b, gam, bet)]
+    xo, wo, bo, go, beo = xs
+    if dtype == torch.float32:
+        wq = wo
+    else:
+        wq = wo + (wo.detach().to(dtype).double() - wo.detach())   # bf16 weights, straight-through
+    z = orc.conv3x3(xo, wq, bo)
+    y, mean, var = orc.batchnorm_train(z, go, beo)
+    a = torch.relu(y)
+    a.backward(q(gy, dtype).double())
+    return a.detach(), [v.grad for v in xs], mean.detach(), var.detach()
+
+
+CBR_SHAPES = [(2, 1, 8, 16, 16), (2, 3, 8, 16, 16), (2, 8, 32, 16, 16), (1, 32, 16, 24, 40),
+              (2, 16, 64, 8, 8), (1, 64, 8, 32, 32), (2, 24, 8, 8, 8)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", CBR_SHAPES)
+def test_conv_bn_relu(F_, dtype, shape):
+    B, Ci, Co, H, W = shape
+    x = np.maximum(dg.hash_normalish((B, Ci, H, W), 501), 0) if Ci > 3 else dg.hash_normalish((B, Ci, H, W), 501)
+    w = dg.hash_normalish((Co, Ci, 3, 3), 502, std=(2.0 / (9 * Co)) ** 0.5)
+    b = dg.hash_uniform((Co,), 503, -0.1, 0.1)
+    gam = dg.hash_uniform((Co,), 504, 0.5, 1.5)
+    bet = dg.hash_uniform((Co,), 505, -0.2, 0.2)
+    gy = dg.hash_normalish((B, Co, H, W), 506)
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm2d(Co).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(T(w)); conv.bias.copy_(T(b)); bn.weight.copy_(T(gam)); bn.bias.copy_(T(bet))
+    xd = act(x, dtype).requires_grad_(True)
+    a = F_.conv_bn_relu(xd, conv, bn, True)
+    a.backward(act(gy, dtype))
+    ao, grads, mean, var = _cbr_oracle(x, w, b, gam, bet, gy, dtype)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    gtol = 2e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(a, ao) < tol
+    assert rel_err(xd.grad, grads[0]) < gtol
+    assert rel_err(conv.weight.grad, grads[1]) < gtol
+    assert rel_err(bn.weight.grad, grads[3]) < gtol
+    assert rel_err(bn.bias.grad, grads[4]) < gtol
+    # conv-bias gradient is analytically zero: only its scale can be checked
+    assert float(conv.bias.grad.abs().max()) < 1e-2 * float(bn.bias.grad.abs().max()) + 1e-4
+    n = B * H * W
+    assert rel_err(bn.running_mean, 0.1 * mean) < max(tol, 1e-4)
+    assert rel_err(bn.running_var, 0.9 + 0.1 * var * n / (n - 1)) < max(tol, 1e-4)
+    assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("name,c", [("dc_a", dict(B=2, cin=3, mid=8, cout=8, hw=16, seed=11)),
+                                    ("dc_b", dict(B=2, cin=16, mid=4, cout=16, hw=8, seed=12))])
+def test_double_conv_golden(F_, golden, name, c):
+    from medical_image_segmentation_amd.model.utils.modules import DoubleConv
+    g = golden("double_conv")
+    m = DoubleConv(c["cin"], c["cout"], c["mid"])
+    st = mg.orc_double_conv_state(c["cin"], c["mid"], c["cout"], c["seed"])
+    m.load_state_dict({k[4:]: v.clone() for k, v in st.items()})
+    m.to(DEV).train()
+    x = dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)
+    gy = dg.hash_normalish((c["B"], c["cout"], c["hw"], c["hw"]), c["seed"] + 200)
+    xd = act(x).requires_grad_(True)
+    y = m(xd)
+    y.backward(act(gy))
+    assert rel_err(y, g[f"{name}.train_y"]) < 2e-5
+    assert rel_err(xd.grad, g[f"{name}.dx"]) < 2e-4
+    for k, p in m.named_parameters():
+        if k.endswith(".0.bias"):
+            continue
+        assert rel_err(p.grad, g[f"{name}.grad.{k}"]) < 5e-4, k
+    for k, b in m.named_buffers():
+        assert rel_err(b.float(), g[f"{name}.buf.{k}"]) < 1e-5, k
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(xd.detach()), g[f"{name}.eval_y"]) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 32, 4, 16, 16), (1, 8, 9, 8, 24), (2, 16, 2, 8, 8)])
+def test_conv1x1(F_, dtype, shape):
+    B, Ci, Co, H, W = shape
+    x = dg.hash_normalish((B, Ci, H, W), 601)
+    w = dg.hash_normalish((Co, Ci, 1, 1), 602, std=0.3)
+    b = dg.hash_uniform((Co,), 603, -0.1, 0.1)
+    gy = dg.hash_normalish((B, Co, H, W), 604)
+    wd, bd = T(w).to(DEV).requires_grad_(True), T(b).to(DEV).requires_grad_(True)
+    xd = act(x, dtype).requires_grad_(True)
+    y = F_.Conv1x1Fn.apply(xd, wd, bd)
+    y.backward(act(gy, dtype))
+    xo = q(x, dtype).double().requires_grad_(True)
+    wo, bo = T(w).double().requires_grad_(True), T(b).double().requires_grad_(True)
+    yo = torch.nn.functional.conv2d(xo, wo, bo)
+    yo.backward(q(gy, dtype).double())
+    tol = TOL[dtype]
+    assert rel_err(y, yo) < tol
+    assert rel_err(xd.grad, xo.grad) < tol
+    assert rel_err(wd.grad, wo.grad) < 5 * tol
+    assert rel_err(bd.grad, bo.grad) < 5 * tol
