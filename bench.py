@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the U-Net training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one full training pass over one synthetic batch: forward, fused Dice loss +
+confusion counts, backward, gradient all-reduce (N > 1), clip_grad_norm_(1.0), AdamW.
+Workload at every N: UNet(in=1, classes=4, base=32), bfloat16 compute, 16 x 512x512 images
+per GPU (BASELINE.json configs[1]; N > 1 is configs[2], weak scaling).  Inputs are resident
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the kernel family with the largest share of a step, timed with HIP events on
+                the launch stream in an instrumented replay of the same steps;
+  cpu_baseline  the CPU restatement of the reference step (oracle/) on the host cores, on a
+                bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak (spec)
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(size, threads):
+    """The oracle's train_step (reference semantics, fp32, torch CPU) on a bounded sample:
+    2 images of the same 512x512 workload per step, 1 warm-up + 2 timed steps."""
+    from oracle import unet_oracle as orc
+    if threads <= 0:
+        threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    B = 2
+    g = torch.Generator().manual_seed(0)
+    st = orc.make_state(1, 4, base=32, seed=1)
+    ts = orc.TrainState(st)
+    x = torch.randn(B, 1, size, size, generator=g)
+    t = torch.randint(0, 4, (B, size, size), generator=g)
+    timers = {}
+    orc.train_step(ts, x, t, ["a", "b", "c"])
+    n = 2
+    t0 = time.perf_counter()
+    for _ in range(n):
+        orc.train_step(ts, x, t, ["a", "b", "c"], timers=timers)
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} timed steps (after 1 warm-up) of batch {B} at {size}x{size}, fp32, torch CPU "
+                      f"restatement of the reference step",
+            "phase_ms_per_step": {k: round(1e3 * v / n, 1) for k, v in timers.items()}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from medical_image_segmentation_amd import _lib, functional as F_
+    _lib.load()
+    from medical_image_segmentation_amd.model.unet import UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    from medical_image_segmentation_amd.utils.metrics import Metrics
+    from medical_image_segmentation_amd.parallel import GradSync
+
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    names = ["a", "b", "c"]
+    torch.manual_seed(1234)
+    model = UNet(1, 4, 0, base_channels=32, compute_dtype=cdt).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=8e-4, betas=(0.95, 0.999), weight_decay=1e-4)
+    sync = None
+    if world > 1:
+        sync = GradSync(model)
+        sync.broadcast_parameters()
+    loss_fn, metric = diceloss(names), Metrics(names)
+    g = torch.Generator(device="cpu").manual_seed(100 + rank)
+    B, S = args.batch, args.size
+    images = torch.randn(B, 1, S, S, generator=g).to(dev)
+    masks = torch.randint(0, 4, (B, S, S), generator=g).to(dev)
+    params = [p for p in model.parameters()]
+    pending = []
+
+    def step():
+        opt.zero_grad()
+        logits = model(images)
+        ld = loss_fn(logits, masks)
+        pending.append(metric.confusion_counts(logits, masks))
+        if sync is not None:
+            sync.begin_step()
+        ld["total_loss"].backward()
+        if sync is not None:
+            sync.finish_step()
+        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+        opt.step()
+        return ld
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    pending.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ld = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_val = float(ld["total_loss"])
+    # host post-math of the metrics for the timed steps (outside the timed region: the counts
+    # were produced inside it)
+    from medical_image_segmentation_amd.utils.train_and_eval import _finish_metrics
+    met = _finish_metrics(metric, pending, 4) / max(len(pending), 1)
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        F_.PROFILE = {}
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        roof = F_.profile_summary(PEAK_HBM_GBS, PEAK_BF16_TFLOPS, steps=3)
+        F_.PROFILE = None
+
+    if rank == 0:
+        out = {
+            "metric": "train images/sec U-Net 512^2 fwd+bwd+Dice/CE",
+            "value": round(B * world * args.steps / dt, 2),
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"UNet(in=1,classes=4,base=32) train step, batch {B}/GPU, {S}x{S}, "
+                                   f"Dice loss + confusion counts + clip + AdamW",
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "final_loss": round(loss_val, 6),
+            "mean_dice": round(float(met[2, -1]), 6),
+        }
+        if roof is not None:
+            out["roofline"] = roof["dominant"]
+            out["kernels"] = roof["kernels"]
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(S, args.cpu_threads)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

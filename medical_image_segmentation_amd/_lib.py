@@ -8,6 +8,10 @@ call fails, a RuntimeError is raised — the reference signals errors by excepti
 import ctypes as C
 import os
 
+# torch ships its own HIP runtime (libamdhip64): importing it first makes libmisamd.so bind
+# to that same runtime instance, so both see the same devices, streams and allocations.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmisamd.so")
 

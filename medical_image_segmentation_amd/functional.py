@@ -70,6 +70,61 @@ def workspace(nbytes, device):
 
 
 # ---------------------------------------------------------------------------
+# optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+# ---------------------------------------------------------------------------
+PROFILE = None        # None = off; a dict = collect {family: [(start_event, end_event, flops, bytes), ...]}
+
+
+class _prof:
+    __slots__ = ("name", "flops", "nbytes", "e0")
+
+    def __init__(self, name, flops, nbytes):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.setdefault(self.name, []).append((self.e0, e1, self.flops, self.nbytes))
+        return False
+
+
+def profile_summary(peak_hbm_gbs, peak_tflops, steps=1):
+    """Per kernel family: time per step, algorithmic GB/s and TFLOP/s, and the roofline
+    object of the family with the largest time share."""
+    fams = {}
+    for name, recs in (PROFILE or {}).items():
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+        fl = sum(r[2] for r in recs)
+        by = sum(r[3] for r in recs)
+        fams[name] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": len(recs) // steps,
+                      "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                      "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 and fl else None,
+                      "alg_bytes_per_step": by // steps, "alg_flops_per_step": fl // steps}
+    if not fams:
+        return {"dominant": None, "kernels": {}}
+    dom = max(fams, key=lambda k: fams[k]["ms_per_step"])
+    d = fams[dom]
+    t_hbm = d["alg_bytes_per_step"] / (peak_hbm_gbs * 1e9)
+    t_mfma = d["alg_flops_per_step"] / (peak_tflops * 1e12)
+    if t_mfma > t_hbm:
+        roof = {"bound": "mfma", "achieved": d["TFLOPs"], "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": round(d["TFLOPs"] / peak_tflops, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": d["GBps"], "peak": peak_hbm_gbs, "unit": "GB/s",
+                "frac": round(d["GBps"] / peak_hbm_gbs, 4)}
+    roof.update({"kernel": dom, "avg_launch_ms": round(d["ms_per_step"] / max(d["launches_per_step"], 1), 4),
+                 "launches_per_step": d["launches_per_step"], "traffic": None})
+    return {"dominant": roof, "kernels": fams}
+
+
+# ---------------------------------------------------------------------------
 # raw ops (no autograd)
 # ---------------------------------------------------------------------------
 def pack_weights(w, dtype, fwd=True, dgrad=False):
@@ -87,9 +142,11 @@ def conv3x3_raw(x, w_packed, bias, Cout, want_stats):
     z = _empty_act(B, Cout, H, W, x)
     stats = torch.empty((2, Cout), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Cout), x.device)
-    call("mis_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
-         _dt(x), B, H, W, Cin, Cout, z.data_ptr(), stats.data_ptr() if want_stats else None, ws.data_ptr(),
-         _stream())
+    es = x.element_size()
+    with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, (B * H * W * (Cin + Cout) + 9 * Cin * Cout) * es):
+        call("mis_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+             _dt(x), B, H, W, Cin, Cout, z.data_ptr(), stats.data_ptr() if want_stats else None, ws.data_ptr(),
+             _stream())
     return z, stats
 
 
@@ -98,8 +155,10 @@ def conv3x3_wgrad_raw(x, dz):
     Cout = dz.shape[1]
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
     ws = workspace(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), x.device)
-    call("mis_conv3x3_wgrad", x.data_ptr(), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout, dw.data_ptr(),
-         ws.data_ptr(), _stream())
+    with _prof("conv3x3_wgrad", 18 * B * H * W * Cin * Cout,
+               B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout):
+        call("mis_conv3x3_wgrad", x.data_ptr(), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout, dw.data_ptr(),
+             ws.data_ptr(), _stream())
     return dw
 
 
@@ -107,7 +166,8 @@ def channel_sum_raw(x):
     B, Cc, H, W = x.shape
     out = torch.empty(Cc, dtype=torch.float32, device=x.device)
     ws = workspace(query("mis_channel_sum_workspace_bytes", B * H * W, Cc), x.device)
-    call("mis_channel_sum", x.data_ptr(), _dt(x), B * H * W, Cc, out.data_ptr(), ws.data_ptr(), _stream())
+    with _prof("channel_sum", 0, x.numel() * x.element_size()):
+        call("mis_channel_sum", x.data_ptr(), _dt(x), B * H * W, Cc, out.data_ptr(), ws.data_ptr(), _stream())
     return out
 
 
@@ -141,7 +201,8 @@ class ConvBnReluFn(torch.autograd.Function):
             mr[0].copy_(running_mean)
             mr[1].copy_(torch.rsqrt(running_var + eps))
         a = _empty_act(B, Cout, H, W, x)
-        call("mis_bn_relu_apply", z.data_ptr(), _dt(x), n_pix, Cout, ss.data_ptr(), a.data_ptr(), st)
+        with _prof("bn_relu_apply", 0, 2 * z.numel() * z.element_size()):
+            call("mis_bn_relu_apply", z.data_ptr(), _dt(x), n_pix, Cout, ss.data_ptr(), a.data_ptr(), st)
         ctx.save_for_backward(x, z, weight, gamma, beta, mr)
         ctx.training = training
         ctx.has_bias = bias is not None
@@ -157,14 +218,16 @@ class ConvBnReluFn(torch.autograd.Function):
         st = _stream()
         sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         ws = workspace(query("mis_bn_relu_bwd_workspace_bytes", n_pix, Cout), x.device)
-        call("mis_bn_relu_bwd_reduce", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
-             gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ws.data_ptr(), st)
+        with _prof("bn_relu_bwd_reduce", 0, 2 * z.numel() * z.element_size()):
+            call("mis_bn_relu_bwd_reduce", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
+                 gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ws.data_ptr(), st)
         dgamma, dbeta = sums[1].clone(), sums[0].clone()
         # eval mode: statistics are constants, so the two projection terms vanish
         proj = sums if ctx.training else torch.zeros_like(sums)
         dz = torch.empty_like(z)
-        call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
-             gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(), st)
+        with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
+            call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
+                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(), st)
         dbias = channel_sum_raw(dz) if ctx.has_bias and ctx.needs_input_grad[2] else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -192,7 +255,8 @@ class MaxPool2x2Fn(torch.autograd.Function):
         if H % 2 or W % 2:
             raise ValueError(f"max-pool 2x2 needs even H and W, got {H}x{W}")
         y = _empty_act(B, Cc, H // 2, W // 2, x)
-        call("mis_maxpool2x2_fwd", x.data_ptr(), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
+        with _prof("maxpool2x2_fwd", 0, (x.numel() + y.numel()) * x.element_size()):
+            call("mis_maxpool2x2_fwd", x.data_ptr(), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
         ctx.save_for_backward(x)
         return y
 
@@ -202,7 +266,8 @@ class MaxPool2x2Fn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         dy = to_act(dy, x.dtype)
         dx = torch.empty_like(x)
-        call("mis_maxpool2x2_bwd", x.data_ptr(), dy.data_ptr(), _dt(x), B, H, W, Cc, dx.data_ptr(), _stream())
+        with _prof("maxpool2x2_bwd", 0, (2 * x.numel() + dy.numel()) * x.element_size()):
+            call("mis_maxpool2x2_bwd", x.data_ptr(), dy.data_ptr(), _dt(x), B, H, W, Cc, dx.data_ptr(), _stream())
         return dx
 
 
@@ -218,8 +283,9 @@ class UpsampleCatFn(torch.autograd.Function):
         if (Bs, Hs, Ws) != (B, 2 * h, 2 * w) or skip.dtype != low.dtype:
             raise ValueError(f"skip {tuple(skip.shape)} does not match upsampled {(B, Cup, 2 * h, 2 * w)}")
         out = _empty_act(B, Cup + Cskip, 2 * h, 2 * w, low)
-        call("mis_upsample2x_cat_fwd", low.data_ptr(), skip.data_ptr(), _dt(low), B, h, w, Cup, Cskip,
-             out.data_ptr(), _stream())
+        with _prof("upsample2x_cat_fwd", 0, (low.numel() + skip.numel() + out.numel()) * low.element_size()):
+            call("mis_upsample2x_cat_fwd", low.data_ptr(), skip.data_ptr(), _dt(low), B, h, w, Cup, Cskip,
+                 out.data_ptr(), _stream())
         ctx.dims = (B, h, w, Cup, Cskip)
         return out
 
@@ -229,8 +295,9 @@ class UpsampleCatFn(torch.autograd.Function):
         dout = to_act(dout)
         dlow = _empty_act(B, Cup, h, w, dout)
         dskip = _empty_act(B, Cskip, 2 * h, 2 * w, dout)
-        call("mis_upsample2x_cat_bwd", dout.data_ptr(), _dt(dout), B, h, w, Cup, Cskip, dlow.data_ptr(),
-             dskip.data_ptr(), _stream())
+        with _prof("upsample2x_cat_bwd", 0, (dout.numel() + dlow.numel() + dskip.numel()) * dout.element_size()):
+            call("mis_upsample2x_cat_bwd", dout.data_ptr(), _dt(dout), B, h, w, Cup, Cskip, dlow.data_ptr(),
+                 dskip.data_ptr(), _stream())
         return dlow, dskip
 
 
@@ -243,8 +310,9 @@ class Conv1x1Fn(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
         y = _empty_act(B, Cout, H, W, x)
-        call("mis_conv1x1_fwd", x.data_ptr(), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
-             bias.data_ptr() if bias is not None else None, y.data_ptr(), _stream())
+        with _prof("conv1x1_fwd", 2 * B * H * W * Cin * Cout, (x.numel() + y.numel()) * x.element_size()):
+            call("mis_conv1x1_fwd", x.data_ptr(), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
+                 bias.data_ptr() if bias is not None else None, y.data_ptr(), _stream())
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -259,8 +327,9 @@ class Conv1x1Fn(torch.autograd.Function):
         dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
         ws = workspace(query("mis_conv1x1_bwd_workspace_bytes", B * H * W, Cin, Cout), x.device)
-        call("mis_conv1x1_bwd", x.data_ptr(), dy.data_ptr(), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
-             dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream())
+        with _prof("conv1x1_bwd", 4 * B * H * W * Cin * Cout, (2 * x.numel() + dy.numel()) * x.element_size()):
+            call("mis_conv1x1_bwd", x.data_ptr(), dy.data_ptr(), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
+                 dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream())
         return dx, dw, (db if ctx.has_bias else None)
 
 
@@ -300,8 +369,9 @@ def loss_metrics_raw(logits, target, want_sums=True, want_ce=False, want_cm=True
     status = torch.empty(1, dtype=torch.int32, device=dev)
     ws = workspace(query("mis_loss_metrics_workspace_bytes", B, Cc, H * W), dev)
     p = lambda t: t.data_ptr() if t is not None else None
-    call("mis_loss_metrics_fwd", logits.data_ptr(), _dt(logits), sb, sc, sp, target.data_ptr(), B, Cc, H * W,
-         p(sums), p(ce), p(cm), status.data_ptr(), ws.data_ptr(), _stream())
+    with _prof("loss_metrics_fwd", 0, B * H * W * (Cc * logits.element_size() + 8 + (4 if want_ce else 0))):
+        call("mis_loss_metrics_fwd", logits.data_ptr(), _dt(logits), sb, sc, sp, target.data_ptr(), B, Cc, H * W,
+             p(sums), p(ce), p(cm), status.data_ptr(), ws.data_ptr(), _stream())
     return sums, ce, cm, status, logits, target
 
 
@@ -336,8 +406,9 @@ class DiceLossFn(torch.autograd.Function):
             dce = dce.to(torch.float32).contiguous()
             dce_p = dce.data_ptr()
         dlogits = torch.empty_like(lg)
-        call("mis_loss_bwd", lg.data_ptr(), _dt(lg), sb, sc, sp, tg.data_ptr(), B, Cc, H * W, sums.data_ptr(),
-             w.data_ptr(), ctx.smooth, dce_p, dlogits.data_ptr(), _stream())
+        with _prof("loss_bwd", 0, B * H * W * (2 * Cc * lg.element_size() + 8)):
+            call("mis_loss_bwd", lg.data_ptr(), _dt(lg), sb, sc, sp, tg.data_ptr(), B, Cc, H * W, sums.data_ptr(),
+                 w.data_ptr(), ctx.smooth, dce_p, dlogits.data_ptr(), _stream())
         if dlogits.dtype != ctx.in_dtype:
             dlogits = dlogits.to(ctx.in_dtype)
         return dlogits, None, None, None

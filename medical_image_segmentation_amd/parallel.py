@@ -1,0 +1,102 @@
+"""Data-parallel gradient averaging over RCCL (one process per GPU).
+
+The reference is single-GPU (train.py:75-76 pins CUDA_VISIBLE_DEVICES=0); this is the new
+exchange step the sharded batch needs: the 74 parameter gradients (2.9 M float32 = 11.6 MB)
+are flattened into a few buckets in reverse layer order (out_conv, decoder4 ... encoder1, the
+order backward produces them) and each bucket is all-reduced (average) as soon as its last
+gradient has been accumulated, on the process group's own stream, overlapping the rest of
+the backward pass.  Per-peer messages are bucket/world bytes over the xGMI mesh, i.e.
+latency-bound, hence few large buckets.
+
+BatchNorm statistics stay rank-local (plain data-parallel semantics): the parity target is
+"N reference replicas on N batch shards with averaged gradients".
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, model, n_buckets=3, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in model.parameters() if p.requires_grad]
+        order = list(reversed(params))                       # backward order
+        total = sum(p.numel() for p in order)
+        target = (total + n_buckets - 1) // n_buckets
+        self.buckets = []
+        cur, cur_n = [], 0
+        for p in order:
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= target:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
+                     for b in self.buckets]
+        self.bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self.bucket_of[p] = bi
+        self.ready = [0] * len(self.buckets)
+        self.handles = [None] * len(self.buckets)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        model._mis_grad_sync = self
+        self.model = model
+
+    def broadcast_parameters(self, src=0):
+        """Start every replica from rank `src`'s parameters and buffers."""
+        if self.world == 1:
+            return
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            dist.broadcast(t.data, src=src, group=self.group)
+
+    def begin_step(self):
+        self.ready = [0] * len(self.buckets)
+        self.handles = [None] * len(self.buckets)
+
+    def _launch(self, bi):
+        b, flat = self.buckets[bi], self.flat[bi]
+        views = flat.split([p.numel() for p in b])
+        torch._foreach_copy_(list(views), [p.grad.reshape(-1) for p in b])
+        if self.world > 1:
+            self.handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if flat.is_cuda else dist.ReduceOp.SUM,
+                                               group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        bi = self.bucket_of[p]
+        self.ready[bi] += 1
+        if self.ready[bi] == len(self.buckets[bi]):
+            self._launch(bi)
+
+    def finish_step(self):
+        """Wait for the buckets and scatter the averaged values back into p.grad."""
+        for bi, b in enumerate(self.buckets):
+            if self.ready[bi] != len(b):          # a parameter received no gradient this step
+                for p in b:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                self._launch(bi)
+            if self.handles[bi] is not None:
+                self.handles[bi].wait()
+            flat = self.flat[bi]
+            if self.world > 1 and not flat.is_cuda:
+                flat.div_(self.world)             # gloo has no AVG
+            if self.world > 1:
+                views = flat.split([p.numel() for p in b])
+                torch._foreach_copy_([p.grad.reshape(-1) for p in b], list(views))
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        if getattr(self.model, "_mis_grad_sync", None) is self:
+            del self.model._mis_grad_sync
+
+
+def all_reduce_dice_sums(sums, group=None):
+    """Global-batch Dice needs the pooled sums of every rank before the ratio is formed
+    (utils/loss_fn.py:79-80 pools over the whole batch): 3*C floats, summed in place."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums

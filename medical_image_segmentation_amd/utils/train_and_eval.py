@@ -1,0 +1,118 @@
+"""train_one_epoch / evaluate — drop-ins for the reference's utils/train_and_eval.py:44-124
+and :242-296: same arguments, same batch format (data[0][0]=images, data[0][1]=masks,
+data[1]=names), same return values (per-class loss list with the total last, and the
+(6, n+1) metric matrix averaged over batches).
+
+Differences that do not change results:
+  * autocast runs in bfloat16 (no loss scaling needed); a GradScaler passed by the caller is
+    honoured if it is enabled, exactly as the reference calls it (train_and_eval.py:111-119);
+  * the confusion counts of every batch stay on the GPU and the reference's float post-math
+    runs once per epoch on the host, so the step loop has no device->host synchronisation
+    (the reference synchronises 7*(n+1) times per batch through .item());
+  * per-batch losses are accumulated detached (the reference keeps graph-attached tensors);
+  * with a GradSync (data parallel) attached to the model, gradients are averaged across
+    ranks before unscale/clip, overlapped with the backward pass.
+"""
+import numpy as np
+import torch
+from torch.amp import autocast
+
+try:
+    from tqdm import tqdm
+except ImportError:          # progress bar only
+    def tqdm(it, **kw):
+        return it
+
+
+def _grad_sync(model):
+    return getattr(model, "_mis_grad_sync", None)
+
+
+def _finish_metrics(Metric, pending, n_rows):
+    """pending: list of (cm, status) device tensors, one per batch -> summed metric matrix."""
+    total = np.zeros((6, n_rows))
+    if not pending:
+        return total
+    flat = torch.cat([torch.cat([cm.reshape(-1), st.to(torch.int64)]) for cm, st in pending]).cpu()
+    off = 0
+    for cm, _ in pending:
+        n = cm.numel()
+        if int(flat[off + n]) != 0:
+            raise RuntimeError("Class values must be smaller than num_classes.")
+        total += Metric.from_counts(flat[off:off + n].reshape(cm.shape))
+        off += n + 1
+    return total
+
+
+def train_one_epoch(model, optimizer, epoch, train_dataloader, device, loss_fn, scaler, Metric, scheduler,
+                    class_names, elnloss, l1_lambda, l2_lambda):
+    model.train()
+    n_batches = len(train_dataloader)
+    loader = tqdm(train_dataloader, desc=f" Training on Epoch :{epoch + 1}", leave=False)
+    epoch_losses = None
+    pending = []
+    sync = _grad_sync(model)
+    use_scaler = scaler is not None and scaler.is_enabled()
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    for data in loader:
+        images, masks = data[0][0], data[0][1]
+        images, masks = images.to(device, non_blocking=True), masks.to(device, non_blocking=True)
+        optimizer.zero_grad()
+        with autocast(device_type="cuda", dtype=torch.bfloat16):
+            pred = model(images)
+            masks = masks.to(torch.int64)
+            loss_dict = loss_fn(pred, masks)
+            losses = list(loss_dict.values())
+            total_loss = loss_dict["total_loss"]
+            if elnloss:
+                total_loss = total_loss + model.elastic_net(l1_lambda=l1_lambda, l2_lambda=l2_lambda)
+            pending.append(Metric.confusion_counts(pred, masks))
+        if sync is not None:
+            sync.begin_step()
+        if use_scaler:
+            scaler.scale(total_loss).backward()
+        else:
+            total_loss.backward()
+        if sync is not None:
+            sync.finish_step()
+        if use_scaler:
+            scaler.unscale_(optimizer)
+        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+        if use_scaler:
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            optimizer.step()
+        scheduler.step()
+        vals = torch.stack([l.detach().float() for l in losses])
+        epoch_losses = vals if epoch_losses is None else epoch_losses + vals
+
+    Metric_list = _finish_metrics(Metric, pending, len(class_names) + 1) / max(n_batches, 1)
+    if epoch_losses is None:
+        return [0.0] * (len(class_names) + 1), Metric_list
+    return list(epoch_losses.unbind(0)), Metric_list
+
+
+def evaluate(model, device, data_loader, loss_fn, Metric, class_names, test: bool = False):
+    model.eval()
+    n_batches = len(data_loader)
+    epoch_losses = None
+    pending = []
+    with torch.no_grad():
+        loader = tqdm(data_loader, desc="  Validating ", leave=False)
+        for data in loader:
+            images, masks = data[0][0].to(device, non_blocking=True), data[0][1].to(device, non_blocking=True)
+            with autocast(device_type="cuda", dtype=torch.bfloat16):
+                pred_mask = model(images)
+                masks = masks.to(torch.int64)
+                masks = masks.squeeze(1)
+                loss_dict = loss_fn(pred_mask, masks)
+                losses = list(loss_dict.values())
+                pending.append(Metric.confusion_counts(pred_mask, masks))
+            vals = torch.stack([l.detach().float() for l in losses])
+            epoch_losses = vals if epoch_losses is None else epoch_losses + vals
+    Metric_list = _finish_metrics(Metric, pending, len(class_names) + 1) / max(n_batches, 1)
+    if epoch_losses is None:
+        return [0.0] * (len(class_names) + 1), Metric_list
+    return list(epoch_losses.unbind(0)), Metric_list

@@ -249,17 +249,45 @@ def test_upsample_cat_random(F_, dtype, shape):
 # ---------------------------------------------------------------------------
 # conv + BN + ReLU, 1x1 conv
 # ---------------------------------------------------------------------------
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose incoming gradient is rounded to `dtype` (a tensor the kernels store)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+def _rnd(t, dtype):
+    """Round values to `dtype`, straight-through for the gradient."""
+    return t + (t.detach().to(dtype).to(t.dtype) - t.detach())
+
+
 def _cbr_oracle(x, w, b, gam, bet, gy, dtype):
-    """float64 oracle of one conv+BN(train)+ReLU with the inputs rounded to `dtype`."""
-    xs = [q(v, dtype).double().requires_grad_(True) for v in (x, w, b, gam, bet)]
+    """float64 oracle of one conv+BN(train)+ReLU with the inputs rounded to `dtype`.
+    In bfloat16 mode it also rounds the tensors the kernels store in bfloat16 — the packed
+    weights, the conv output z (statistics are taken before that rounding, from the float32
+    accumulators), the activation a and the gradient dz — so the comparison isolates kernel
+    errors from the storage format's own rounding."""
+    # parameters stay float32 masters (only the packed conv weights are rounded, below)
+    xs = [q(x, dtype).double().requires_grad_(True)] + [T(v).double().requires_grad_(True) for v in (w, b, gam, bet)]
     xo, wo, bo, go, beo = xs
     if dtype == torch.float32:
-        wq = wo
+        z = orc.conv3x3(xo, wo, bo)
+        y, mean, var = orc.batchnorm_train(z, go, beo)
+        a = torch.relu(y)
     else:
-        wq = wo + (wo.detach().to(dtype).double() - wo.detach())   # bf16 weights, straight-through
-    z = orc.conv3x3(xo, wq, bo)
-    y, mean, var = orc.batchnorm_train(z, go, beo)
-    a = torch.relu(y)
+        z = orc.conv3x3(xo, _rnd(wo, dtype), bo)
+        mean = z.mean(dim=(0, 2, 3))
+        var = z.var(dim=(0, 2, 3), unbiased=False)
+        zr = _rnd(_RoundGrad.apply(z, dtype), dtype)
+        rstd = torch.rsqrt(var + orc.BN_EPS)
+        y = (zr - mean[None, :, None, None]) * (rstd * go)[None, :, None, None] + beo[None, :, None, None]
+        a = _rnd(torch.relu(y), dtype)
     a.backward(q(gy, dtype).double())
     return a.detach(), [v.grad for v in xs], mean.detach(), var.detach()
 
@@ -294,7 +322,7 @@ def test_conv_bn_relu(F_, dtype, shape):
     assert rel_err(bn.weight.grad, grads[3]) < gtol
     assert rel_err(bn.bias.grad, grads[4]) < gtol
     # conv-bias gradient is analytically zero: only its scale can be checked
-    assert float(conv.bias.grad.abs().max()) < 1e-2 * float(bn.bias.grad.abs().max()) + 1e-4
+    assert float(conv.bias.grad.abs().max()) < (1e-3 if dtype == torch.float32 else 5e-2) * float(bn.bias.grad.abs().max()) + 1e-4
     n = B * H * W
     assert rel_err(bn.running_mean, 0.1 * mean) < max(tol, 1e-4)
     assert rel_err(bn.running_var, 0.9 + 0.1 * var * n / (n - 1)) < max(tol, 1e-4)

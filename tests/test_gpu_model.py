@@ -1,0 +1,138 @@
+"""GPU suite: whole-model parity — UNet forward/backward, the training harness and the
+evaluation loop against the golden vectors produced by the reference, in float32 mode (the
+reference's CPU path) and bfloat16 mode (the benchmark's compute type)."""
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from oracle import datagen as dg
+from oracle import unet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else T(np.asarray(b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def build(c, dtype):
+    from medical_image_segmentation_amd.model.unet import UNet
+    m = UNet(c["cin"], c["ncls"], 0, base_channels=8, compute_dtype=dtype)
+    st = orc.make_state(c["cin"], c["ncls"], base=8, seed=c["seed"])
+    assert list(m.state_dict().keys()) == list(st.keys())
+    m.load_state_dict({k: v.clone() for k, v in st.items()})
+    return m.to(DEV)
+
+
+UNET_CASES = [("unet_a", dict(B=2, cin=1, ncls=4, hw=32, seed=21)),
+              ("unet_b", dict(B=2, cin=3, ncls=4, hw=64, seed=22)),
+              ("unet_c", dict(B=1, cin=1, ncls=9, hw=32, seed=23))]
+
+
+@pytest.mark.parametrize("name,c", UNET_CASES)
+def test_unet_fp32_golden(golden, name, c):
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    g = golden("unet")
+    m = build(c, torch.float32).train()
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(DEV)
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)).to(DEV)
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    logits = m(x)
+    assert logits.shape == (c["B"], c["ncls"], c["hw"], c["hw"]) and logits.dtype == torch.float32
+    ld = diceloss(names)(logits, t)
+    ld["total_loss"].backward()
+    assert rel_err(logits, g[f"{name}.logits"]) < 1e-4            # float32 mode: 1e-5 class, deep net
+    np.testing.assert_allclose([float(v.detach()) for v in ld.values()], g[f"{name}.loss"], rtol=1e-5, atol=1e-6)
+    params = dict(m.named_parameters())
+    keys = list(g[f"{name}.grad_keys"])
+    assert keys == list(params.keys())
+    norms = np.array([float(params[k].grad.double().norm()) for k in keys])
+    is_cb = np.array([k.endswith(".0.bias") and k != "out_conv.bias" for k in keys])
+    np.testing.assert_allclose(norms[~is_cb], g[f"{name}.grad_norms"][~is_cb], rtol=5e-3, atol=1e-7)
+    samp = np.stack([params[k].grad.detach().cpu().numpy().reshape(-1)[mg.sample_idx(params[k].numel())] for k in keys])
+    scale = np.array([float(params[k].grad.abs().max()) for k in keys])[:, None]
+    assert (np.abs(samp - g[f"{name}.grad_samples"])[~is_cb] / scale[~is_cb]).max() < 5e-3
+    assert rel_err(m.center_conv.cbr1[1].running_mean, g[f"{name}.running_mean.center_conv.cbr1"]) < 1e-4
+    assert rel_err(m.center_conv.cbr1[1].running_var, g[f"{name}.running_var.center_conv.cbr1"]) < 1e-4
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(x), g[f"{name}.eval_logits"]) < 1e-4
+
+
+@pytest.mark.parametrize("name,c", UNET_CASES)
+def test_unet_bf16_within_1e2(golden, name, c):
+    """bfloat16 compute against the float32 reference: loss and logits within 1e-2 relative."""
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    g = golden("unet")
+    m = build(c, torch.bfloat16).train()
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(DEV)
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)).to(DEV)
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    logits = m(x)
+    assert logits.dtype == torch.bfloat16
+    ld = diceloss(names)(logits, t)
+    ld["total_loss"].backward()
+    ref = T(g[f"{name}.logits"]).double()
+    l2 = float((logits.double().cpu() - ref).norm() / ref.norm())
+    assert l2 < 1e-2, l2
+    np.testing.assert_allclose([float(v.detach()) for v in ld.values()], g[f"{name}.loss"], rtol=1e-2)
+    # gradients: direction agrees with the float32 reference
+    params = dict(m.named_parameters())
+    gw = params["out_conv.weight"].grad.double().cpu().reshape(-1)
+    rw = T(g[f"{name}.grad.out_conv.weight"]).double().reshape(-1)
+    assert float(torch.dot(gw, rw) / (gw.norm() * rw.norm())) > 0.99
+
+
+def test_autocast_selects_bf16():
+    c = UNET_CASES[0][1]
+    m = build(c, None).eval()
+    x = torch.zeros(1, 1, 32, 32, device=DEV)
+    with torch.no_grad():
+        assert m(x).dtype == torch.float32
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert m(x).dtype == torch.bfloat16
+
+
+def test_train_one_epoch_and_evaluate_golden(golden):
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    from medical_image_segmentation_amd.utils.metrics import Metrics
+    from medical_image_segmentation_amd.utils.train_and_eval import train_one_epoch, evaluate
+    g = golden("train")
+    c = mg.train_case()
+    m = build(c, torch.float32)
+    names = ["a", "b", "c"]
+    opt = torch.optim.AdamW(m.parameters(), lr=c["lr"], betas=(0.95, 0.999), weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+    scaler = torch.amp.GradScaler("cuda", enabled=False)
+    loader = [((T(x), T(t)), [f"img{i}"]) for i, (x, t) in enumerate(mg.train_batches(c))]
+    losses, mets = train_one_epoch(m, opt, 0, loader, torch.device(DEV), diceloss(names), scaler, Metrics(names),
+                                   sched, names, False, 0.0, 0.0)
+    assert len(losses) == 4 and mets.shape == (6, 4)
+    np.testing.assert_allclose([float(v) for v in losses], g["train.losses"], rtol=2e-4)
+    np.testing.assert_allclose(mets, g["train.metrics"], rtol=0, atol=2e-3)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["train.keys"])
+    flip = 2 * c["lr"] * c["steps"]
+    for k in ("out_conv.weight", "encoder1.cbr1.0.weight"):
+        d = np.abs(sd[k].cpu().numpy() - g["train." + k])
+        assert d.max() <= flip + 1e-5 and (d < 2e-5).mean() > 0.9, (k, d.max(), (d < 2e-5).mean())
+    assert int(sd["encoder1.cbr1.1.num_batches_tracked"]) == c["steps"]
+    el, em = evaluate(m, torch.device(DEV), loader, diceloss(names), Metrics(names), names)
+    np.testing.assert_allclose([float(v) for v in el], g["eval.losses"], rtol=2e-3)
+    np.testing.assert_allclose(em, g["eval.metrics"], rtol=0, atol=1e-2)
+
+
+def test_checkpoint_roundtrip_with_reference_keys(tmp_path):
+    c = UNET_CASES[0][1]
+    m = build(c, torch.float32)
+    path = tmp_path / "ck.pth"
+    torch.save({"model": m.state_dict()}, path)
+    sd = torch.load(path, weights_only=True)["model"]
+    assert len(sd) == 128
+    m2 = build(c, torch.float32)
+    m2.load_state_dict(sd)
