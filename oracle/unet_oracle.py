@@ -184,6 +184,38 @@ def unet_forward(x, state, training=True, update_stats=True):
     return F.conv2d(y, state["out_conv.weight"], state["out_conv.bias"])   # unet.py:44,84
 
 
+def unet_forward_bf16_storage(x, state):
+    """Training-mode forward in float64 arithmetic with every tensor the bfloat16 compute
+    mode STORES in bfloat16 rounded at that point: the image, the packed conv weights, each
+    conv output z (its BatchNorm statistics are taken before the rounding, from the
+    accumulators), each activation, the upsampled tensor and the logits.  It separates the
+    error of the storage format (which any bfloat16 implementation has: about 1-2e-2 relative
+    L2 on the logits from the weight rounding alone, 2.5-3.5e-2 in total on this network) from
+    errors of the kernels."""
+    bf = lambda t: t.to(torch.bfloat16).to(t.dtype)
+
+    def cbr(t, p):
+        z = F.conv2d(t, bf(state[p + ".0.weight"]), state[p + ".0.bias"], padding=1)
+        mean = z.mean(dim=(0, 2, 3))
+        var = z.var(dim=(0, 2, 3), unbiased=False)
+        scale = torch.rsqrt(var + BN_EPS) * state[p + ".1.weight"]
+        y = (bf(z) - mean[None, :, None, None]) * scale[None, :, None, None] + state[p + ".1.bias"][None, :, None, None]
+        return bf(torch.relu(y))
+
+    dc = lambda t, n: cbr(cbr(t, n + ".cbr1"), n + ".cbr2")
+    up = lambda t: bf(upsample2x_bilinear(t))
+    x1 = dc(bf(x), "encoder1")
+    x2 = dc(maxpool2x2(x1), "encoder2")
+    x3 = dc(maxpool2x2(x2), "encoder3")
+    x4 = dc(maxpool2x2(x3), "encoder4")
+    y = dc(maxpool2x2(x4), "center_conv")
+    y = dc(torch.cat([up(y), x4], dim=1), "decoder1")
+    y = dc(torch.cat([up(y), x3], dim=1), "decoder2")
+    y = dc(torch.cat([up(y), x2], dim=1), "decoder3")
+    y = dc(torch.cat([up(y), x1], dim=1), "decoder4")
+    return bf(F.conv2d(y, state["out_conv.weight"], state["out_conv.bias"]))
+
+
 # ----------------------------------------------------------------------------
 # losses
 # ----------------------------------------------------------------------------
