@@ -106,19 +106,27 @@ int mis_upsample2x_cat_bwd(const void* dout, int dtype, int B, int h, int w, int
 /* DoubleConv building block: Conv2d(3x3, pad 1, bias) -> BatchNorm2d -> ReLU   */
 /* (model/utils/modules.py:86-94,97-99).                                        */
 /*                                                                              */
-/* mis_pack_conv3x3_weights: float32 [Cout][Cin][3][3] -> the two operand       */
-/* layouts the conv kernels read, in the activation dtype:                      */
-/*   w_fwd [9][Cout][Cin]  (tap = ky*3+kx)                                       */
-/*   w_dgrad [9][Cin][Cout] with taps mirrored (for dX = conv(dZ, W^T flipped)). */
-/* Either output may be NULL.                                                   */
-int mis_pack_conv3x3_weights(const float* w, int Cout, int Cin, int dtype, void* w_fwd, void* w_dgrad,
+/* mis_pack_conv3x3_weights: float32 master weights [Cout_w][Cin_w][3][3] (nn.Conv2d  */
+/* layout) -> the operand image the conv kernels read, in the activation dtype.     */
+/* transposed = 0: operand of the forward conv (Cin_w -> Cout_w channels);           */
+/* transposed = 1: operand of the data gradient  dX = conv(dZ, W^T, taps mirrored)   */
+/*                 (Cout_w -> Cin_w channels).                                        */
+/* The image layout is private to the library (fragment-ordered for the matrix-core  */
+/* kernels, [9][Cout][Cin] for the vector-ALU ones) and depends only on the channel   */
+/* counts, dtype and the conv path; size it with mis_conv3x3_packed_weight_bytes.     */
+size_t mis_conv3x3_packed_weight_bytes(int Cout_w, int Cin_w, int transposed, int dtype);
+int mis_pack_conv3x3_weights(const float* w, int Cout_w, int Cin_w, int transposed, int dtype, void* out,
                              mis_stream_t stream);
+/* Test hook: 0 = pick the kernel per shape (default), 1 = vector-ALU kernels only.   */
+/* Weights must be re-packed after a change.                                          */
+int mis_set_conv_path(int mode);
 
 /* z = conv3x3(x, w) + bias (bias may be NULL), channels-last, same H,W.        */
 /* If stats is not NULL it receives float32 [2][Cout]: sum z and sum z^2 over   */
 /* (B,H,W), taken from the float32 accumulators (before any rounding to bf16);  */
-/* it needs the workspace.  Used for the forward conv (w_fwd, Cin->Cout) and,   */
-/* with w_dgrad and the channel counts swapped, for the data gradient.          */
+/* it needs the workspace.  Used for the forward conv (transposed=0 image,       */
+/* Cin->Cout) and, with the transposed=1 image and the channel counts swapped,  */
+/* for the data gradient.                                                       */
 size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int mis_conv3x3_fwd(const void* x, const void* w_packed, const float* bias, int dtype,
                     int B, int H, int W, int Cin, int Cout,

@@ -11,13 +11,24 @@
 #include "vec.h"
 #include "reduce.h"
 
+// 256 threads = 8 row lanes x 32 columns: coalesced 128-byte row reads, double accumulation,
+// fixed combination order (bitwise reproducible).
 __global__ void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int n, int64_t stride,
                                        float* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  __shared__ double red[8][32];
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   double s = 0.0;
-  for (int i = 0; i < nblk; i++) s += (double)partials[(int64_t)i * stride + j];
-  out[j] = (float)s;
+  if (j < n)
+    for (int i = r; i < nblk; i += 8) s += (double)partials[(int64_t)i * stride + j];
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0 && j < n) {
+    double t = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; k++) t += red[k][c];
+    out[j] = (float)t;
+  }
 }
 
 namespace {

@@ -4,12 +4,48 @@
 #include "conv_internal.h"
 #include <stdlib.h>
 
+static int g_conv_path = -1;   // -1: read MIS_CONV_FORCE_DIRECT once; 0: auto; 1: vector-ALU kernels only
+
 static bool force_direct() {
-  const char* e = getenv("MIS_CONV_FORCE_DIRECT");
-  return e && e[0] == '1';
+  if (g_conv_path < 0) {
+    const char* e = getenv("MIS_CONV_FORCE_DIRECT");
+    g_conv_path = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_conv_path == 1;
+}
+
+// The packed layout depends only on (dtype, channel counts) so that pack and conv agree.
+static bool use_mfma(int dtype, int Cin, int Cout) {
+  return !force_direct() && conv3x3_mfma_supported(dtype, 1, 16, 16, Cin, Cout);
 }
 
 extern "C" {
+
+int mis_set_conv_path(int mode) {
+  if (mode != 0 && mode != 1) {
+    mis_set_error("set_conv_path: mode must be 0 (auto) or 1 (vector-ALU only)");
+    return MIS_ERR_ARG;
+  }
+  g_conv_path = mode;
+  return MIS_OK;
+}
+
+size_t mis_conv3x3_packed_weight_bytes(int Cout_w, int Cin_w, int transposed, int dtype) {
+  if (Cout_w < 1 || Cin_w < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
+  const int Cin = transposed ? Cout_w : Cin_w, Cout = transposed ? Cin_w : Cout_w;
+  return use_mfma(dtype, Cin, Cout) ? conv3x3_mfma_packed_bytes(dtype, Cin, Cout)
+                                    : conv3x3_direct_packed_bytes(dtype, Cin, Cout);
+}
+
+int mis_pack_conv3x3_weights(const float* w, int Cout_w, int Cin_w, int transposed, int dtype, void* out,
+                             mis_stream_t stream) {
+  MIS_REQUIRE(w && out && Cout_w >= 1 && Cin_w >= 1, "pack_conv3x3_weights: bad arguments");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "pack_conv3x3_weights: bad dtype %d", dtype);
+  const int Cin = transposed ? Cout_w : Cin_w, Cout = transposed ? Cin_w : Cout_w;
+  if (use_mfma(dtype, Cin, Cout))
+    return conv3x3_mfma_pack(w, Cout_w, Cin_w, transposed ? 1 : 0, dtype, out, (hipStream_t)stream);
+  return conv3x3_direct_pack(w, Cout_w, Cin_w, transposed ? 1 : 0, dtype, out, (hipStream_t)stream);
+}
 
 size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
@@ -27,7 +63,7 @@ int mis_conv3x3_fwd(const void* x, const void* w_packed, const float* bias, int 
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_fwd: bad shape");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_fwd: bad dtype %d", dtype);
   MIS_REQUIRE((int64_t)B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < ((int64_t)1 << 40), "conv3x3_fwd: tensor too large");
-  if (!force_direct() && conv3x3_mfma_supported(dtype, B, H, W, Cin, Cout))
+  if (use_mfma(dtype, Cin, Cout))
     return conv3x3_mfma_fwd(x, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace, (hipStream_t)stream);
   return conv3x3_direct_fwd(x, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace, (hipStream_t)stream);
 }

@@ -368,6 +368,23 @@ int conv3x3_direct_fwd(const void* x, const void* wp, const float* bias, int dty
   return MIS_OK;
 }
 
+size_t conv3x3_direct_packed_bytes(int dtype, int Cin, int Cout) {
+  return (size_t)9 * Cin * Cout * (dtype == MIS_BF16 ? 2 : 4);
+}
+
+int conv3x3_direct_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st) {
+  const int64_t n = (int64_t)Cw_out * Cw_in * 9;
+  const int grid = ew_grid(n, 256);
+  if (dtype == MIS_F32)
+    pack_w3x3_kernel<float><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, transposed ? nullptr : (float*)out,
+                                                  transposed ? (float*)out : nullptr);
+  else
+    pack_w3x3_kernel<bf16><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, transposed ? nullptr : (bf16*)out,
+                                                 transposed ? (bf16*)out : nullptr);
+  MIS_CHECK_LAUNCH("pack_w3x3_kernel");
+  return MIS_OK;
+}
+
 int conv3x3_direct_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
                          hipStream_t st) {
   const int64_t n_pix = (int64_t)B * H * W;
@@ -393,20 +410,6 @@ int conv3x3_direct_wgrad(const void* x, const void* dz, int dtype, int B, int H,
 }
 
 extern "C" {
-
-int mis_pack_conv3x3_weights(const float* w, int Cout, int Cin, int dtype, void* w_fwd, void* w_dgrad,
-                             mis_stream_t stream) {
-  MIS_REQUIRE(w && (w_fwd || w_dgrad) && Cout >= 1 && Cin >= 1, "pack_conv3x3_weights: bad arguments");
-  const int64_t n = (int64_t)Cout * Cin * 9;
-  const int grid = ew_grid(n, 256);
-  if (dtype == MIS_F32)
-    pack_w3x3_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, (float*)w_fwd, (float*)w_dgrad);
-  else if (dtype == MIS_BF16)
-    pack_w3x3_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, (bf16*)w_fwd, (bf16*)w_dgrad);
-  else MIS_REQUIRE(false, "pack_conv3x3_weights: bad dtype %d", dtype);
-  MIS_CHECK_LAUNCH("pack_w3x3_kernel");
-  return MIS_OK;
-}
 
 int mis_conv1x1_fwd(const void* x, int dtype, int64_t n_pix, int Cin, int Cout, const float* w, const float* bias,
                     void* y, mis_stream_t stream) {

@@ -1,8 +1,425 @@
-// placeholder until the matrix-core kernels land
+// 3x3 convolution as an implicit GEMM on the gfx950 matrix cores (forward and data gradient).
+//
+//   D[cout][pixel] += W[cout][k] * X[k][pixel],   k = (tap, cin)
+//
+// * Channels-last activations.  A workgroup (4 waves) owns a 16x16 pixel tile and a slice of
+//   16*NT output channels, and walks tiles persistently (grid-stride), so per-channel
+//   statistics are reduced once per workgroup and, when Cin fits one chunk, the weight
+//   slice is staged into LDS once per workgroup instead of once per tile.
+// * The 18x18xKC input halo of a tile is staged through registers into LDS (zero fill =
+//   the conv's padding); every halo element is then reused by the 9 taps from LDS instead
+//   of being fetched 9 times.  Global loads of stage i+1 are issued before the MFMAs of
+//   stage i and written to LDS after them (loads in flight under the matrix work).
+// * K is ordered (tap, cin) in 16-byte groups (8 bf16 / 4 f32 channels).  One MFMA step
+//   takes 4 groups: with KC = 4 groups per position a step is one tap; with fewer channels
+//   (Cin = 8, 16, 24 in bf16) a step spans several taps, so short-K layers do not pad K per
+//   tap.  Weights are pre-packed in exactly the per-lane fragment order (1 KiB per
+//   16-cout x 4-group fragment), so staging is a linear copy and fragment reads are
+//   lane-linear ds_read_b128 (conflict-free).
+// * The weight fragment is the MFMA A operand and the activation fragment the B operand, so
+//   a lane's 4 accumulator registers are 4 consecutive output channels of ONE pixel: the
+//   store is an 8-byte (bf16) or 16-byte (f32) vector per lane, channels-last.
+// * float32 mode uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) with the same data flow:
+//   a lane's 16-byte fragment holds 4 channels and feeds 4 MFMAs.
+//
+// Roofline: min(MFMA, HBM) per layer.  Algorithmic bytes = B*H*W*(Cin+Cout)*sizeof(T);
+// algorithmic flops = 2*9*B*H*W*Cin*Cout.
 #include "conv_internal.h"
-bool conv3x3_mfma_supported(int, int, int, int, int, int) { return false; }
-size_t conv3x3_mfma_workspace_bytes(int, int, int, int, int, int) { return 0; }
-int conv3x3_mfma_fwd(const void*, const void*, const float*, int, int, int, int, int, int, void*, float*, void*, hipStream_t) { return MIS_ERR_UNSUPPORTED; }
+#include "reduce.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16;          // output tile
+constexpr int HW_ = TW + 2;              // halo width
+constexpr int HP = (TH + 2) * HW_;       // halo positions (324)
+constexpr int CM_THREADS = 256;
+constexpr int MT = 4;                    // tile rows (16-pixel MFMA columns) per wave
+
+template <typename T> struct Mf;
+template <> struct Mf<bf16> {
+  static constexpr int G = 8;
+  using Frag = bf16x8;
+};
+template <> struct Mf<float> {
+  static constexpr int G = 4;
+  using Frag = f32x4;
+};
+
+__device__ __forceinline__ void mfma_step(const bf16x8& a, const bf16x8& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_step(const f32x4& a, const f32x4& b, f32x4& c) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+}
+
+constexpr int nsteps_of(int cpg) { return (9 * cpg + 3) / 4; }
+
+// 16-byte slot of (position p, channel group cg) inside the halo image.  With 4 groups per
+// position (64-byte rows) the group index is rotated by 2*(p/4) so that the 16 lanes of one
+// ds_read_b128 service group (16 consecutive positions x one group) hit 16 distinct slots.
+template <int CPG>
+__device__ __forceinline__ int halo_slot(int p, int cg) {
+  if constexpr (CPG == 4) return p * 4 + ((cg + 2 * (p >> 2)) & 3);
+  else return p * CPG + cg;
+}
+
+// Packed weight layout: [chunk][step][n-tile (16 couts)][lane 0..63][G elements]; lane l holds
+// W[cout = 16n + (l&15)][k-group 4*step + (l>>4)], group -> (tap, cg) = (g / CPG, g % CPG).
+template <typename T>
+__global__ void pack_w3x3_frag_kernel(const float* __restrict__ w, int Cw_out, int Cw_in, int transposed,
+                                      int CPG, int n_chunks, int nt_total, T* __restrict__ out) {
+  constexpr int G = Mf<T>::G;
+  const int NS = (9 * CPG + 3) / 4;
+  const int64_t total = (int64_t)n_chunks * NS * nt_total * 64 * G;
+  const int Cout = transposed ? Cw_in : Cw_out;     // channels the conv produces
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % G);
+    const int l = (int)((i / G) % 64);
+    const int n = (int)((i / (G * 64)) % nt_total);
+    const int s = (int)((i / ((int64_t)G * 64 * nt_total)) % NS);
+    const int c = (int)(i / ((int64_t)G * 64 * nt_total * NS));
+    const int g = 4 * s + (l >> 4);
+    const int tap = g / CPG, cg = g % CPG;
+    const int co = 16 * n + (l & 15);
+    const int ci = (c * CPG + cg) * G + j;
+    float v = 0.f;
+    if (tap < 9 && co < Cout) {
+      if (!transposed) v = w[((int64_t)co * Cw_in + ci) * 9 + tap];
+      else v = w[((int64_t)ci * Cw_in + co) * 9 + (8 - tap)];
+    }
+    out[i] = from_f32<T>(v);
+  }
+}
+
+template <typename T, int NT, int CPG>
+__global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
+    const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias, T* __restrict__ z,
+    float* __restrict__ partials, int B, int H, int W, int Cin, int Cout, int n_chunks, int nt_total, int tiles_x,
+    int tiles_y, int n_tiles) {
+  constexpr int G = Mf<T>::G;
+  using Frag = typename Mf<T>::Frag;
+  constexpr int NS = nsteps_of(CPG);
+  constexpr int KC = CPG * G;
+  constexpr int HALO_VECS = HP * CPG;
+  constexpr int HALO_IT = (HALO_VECS + CM_THREADS - 1) / CM_THREADS;
+  constexpr int W_VECS = NS * NT * 64;
+  constexpr int W_IT = (W_VECS + CM_THREADS - 1) / CM_THREADS;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* halo = reinterpret_cast<uint4*>(smem);
+  uint4* wl = halo + HALO_VECS;
+  __shared__ float red[4][2][NT * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, kg = lane >> 4;
+  const int n0 = blockIdx.y * NT;                 // first n-tile of this workgroup
+  const uint4* wsrc = reinterpret_cast<const uint4*>(wp);
+
+  // per-lane tap offsets of each MFMA step (positions inside the halo) and channel group
+  // (with 4 groups per position a step is exactly one tap: offsets are compile-time constants)
+  constexpr int NTAB = (CPG == 4) ? 1 : NS;
+  int tap_off[NTAB], tap_cg[NTAB];
+  if constexpr (CPG != 4) {
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      int g = 4 * s + kg;
+      int tap = g / CPG;
+      tap_cg[s] = g % CPG;
+      if (tap > 8) tap = 8;                        // padded group: weights are zero, read finite data
+      tap_off[s] = (tap / 3) * HW_ + (tap % 3);
+    }
+  }
+
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int n = 0; n < NT; n++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s1[n][r] = s2[n][r] = 0.f;
+
+  uint4 hreg[HALO_IT], wreg[W_IT];
+
+#define LOAD_HALO(TILE, CHUNK)                                                                           \
+  {                                                                                                      \
+    const int t_ = (TILE);                                                                               \
+    const int tx_ = t_ % tiles_x, ty_ = (t_ / tiles_x) % tiles_y, b_ = t_ / (tiles_x * tiles_y);         \
+    const int y0_ = ty_ * TH - 1, x0_ = tx_ * TW - 1;                                                    \
+    _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
+      const int v = tid + i * CM_THREADS;                                                                \
+      const int pos = v / CPG, cg = v % CPG;                                                             \
+      const int gy = y0_ + pos / HW_, gx = x0_ + pos % HW_;                                              \
+      const bool ok = (v < HALO_VECS) && gy >= 0 && gy < H && gx >= 0 && gx < W;                         \
+      const T* src = x + (((int64_t)b_ * H + gy) * W + gx) * Cin + (CHUNK) * KC + cg * G;                \
+      hreg[i] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);                      \
+    }                                                                                                    \
+  }
+#define STORE_HALO()                                                                                     \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
+      const int v = tid + i * CM_THREADS;                                                                \
+      if (v < HALO_VECS) halo[halo_slot<CPG>(v / CPG, v % CPG)] = hreg[i];                               \
+    }                                                                                                    \
+  }
+#define LOAD_W(CHUNK)                                                                                    \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < W_IT; i++) {                                                   \
+      const int v = tid + i * CM_THREADS;                                                                \
+      const int s_ = v / (NT * 64), rem = v % (NT * 64);                                                 \
+      wreg[i] = (v < W_VECS) ? wsrc[((int64_t)((CHUNK) * NS + s_) * nt_total + n0) * 64 + rem]             \
+                             : make_uint4(0, 0, 0, 0);                                                     \
+    }                                                                                                    \
+  }
+#define STORE_W()                                                                                        \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < W_IT; i++) {                                                   \
+      const int v = tid + i * CM_THREADS;                                                                \
+      if (v < W_VECS) wl[v] = wreg[i];                                                                   \
+    }                                                                                                    \
+  }
+
+  const bool w_resident = (n_chunks == 1);
+  int tile = blockIdx.x;
+  if (tile < n_tiles) {
+    LOAD_HALO(tile, 0)
+    LOAD_W(0)
+  }
+  bool first = true;
+  for (; tile < n_tiles; tile += gridDim.x) {
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < n_chunks; chunk++) {
+      __syncthreads();                     // every wave is done reading the previous stage
+      STORE_HALO()
+      if (!w_resident || first) STORE_W()
+      first = false;
+      __syncthreads();
+      // issue the next stage's global loads; they complete under the MFMAs below
+      {
+        int nchunk = chunk + 1, ntile = tile;
+        if (nchunk == n_chunks) {
+          nchunk = 0;
+          ntile = tile + gridDim.x;
+        }
+        if (ntile < n_tiles) {
+          LOAD_HALO(ntile, nchunk)
+          if (!w_resident) LOAD_W(nchunk)
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        Frag xa[MT], wf[NT];
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+          int p = (wid * MT + m) * HW_ + col, cg;
+          if constexpr (CPG == 4) {
+            p += (s / 3) * HW_ + (s % 3);
+            cg = kg;
+          } else {
+            p += tap_off[s];
+            cg = tap_cg[s];
+          }
+          xa[m] = *reinterpret_cast<const Frag*>(&halo[halo_slot<CPG>(p, cg)]);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; n++) wf[n] = *reinterpret_cast<const Frag*>(&wl[(s * NT + n) * 64 + lane]);
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+          for (int m = 0; m < MT; m++) mfma_step(wf[n], xa[m], acc[m][n]);
+      }
+    }
+
+    // epilogue: bias, channels-last store (4 consecutive channels per lane), statistics
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int gx = tx * TW + col;
+    float bv[NT][4];                       // re-read per tile (L1/L2 hit) rather than held in registers
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+      const int co = (n0 + n) * 16 + 4 * kg;
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (bias && co < Cout) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+      for (int r = 0; r < 4; r++) bv[n][r] = b4[r];
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      const int gy = ty * TH + wid * MT + m;
+      const bool pv = (gy < H) && (gx < W);
+      T* zp = z + (((int64_t)b * H + gy) * W + gx) * Cout;
+#pragma unroll
+      for (int n = 0; n < NT; n++) {
+        const int co = (n0 + n) * 16 + 4 * kg;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = acc[m][n][r] + bv[n][r];
+        if (pv && co < Cout) {
+          vstore<T, 4>(zp + co, v);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            s1[n][r] += v[r];
+            s2[n][r] += v[r] * v[r];
+          }
+        }
+      }
+    }
+  }
+
+  if (partials) {
+    // sum over the 16 pixel lanes that share a channel quad, then over the 4 waves
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float a = s1[n][r], q = s2[n][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, WAVE);
+          q += __shfl_xor(q, o, WAVE);
+        }
+        if (col == 0) {
+          red[wid][0][n * 16 + 4 * kg + r] = a;
+          red[wid][1][n * 16 + 4 * kg + r] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * NT * 16) {
+      const int which = tid / (NT * 16), c = tid % (NT * 16);
+      const float v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+      const int co = n0 * 16 + c;
+      if (co < Cout) partials[((int64_t)blockIdx.x * 2 + which) * Cout + co] = v;
+    }
+  }
+}
+
+#undef LOAD_HALO
+#undef STORE_HALO
+#undef LOAD_W
+#undef STORE_W
+
+struct FwdPlan {
+  int CPG, NT, n_chunks, nt_total, grid_x, grid_y, tiles_x, tiles_y, n_tiles;
+  size_t lds;
+};
+
+template <typename T>
+bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
+  constexpr int G = Mf<T>::G;
+  if (Cin % G != 0 || Cout % 4 != 0 || Cin < G) return false;
+  const int groups = Cin / G;
+  if (groups <= 4) {
+    p.CPG = groups;
+    p.n_chunks = 1;
+  } else if (groups % 4 == 0) {
+    p.CPG = 4;
+    p.n_chunks = groups / 4;
+  } else {
+    return false;
+  }
+  p.nt_total = (Cout + 15) / 16;
+  p.NT = p.nt_total >= 4 ? 4 : (p.nt_total >= 2 ? 2 : 1);
+  if (p.nt_total % p.NT != 0) p.NT = (p.nt_total % 2 == 0) ? 2 : 1;
+  p.grid_y = p.nt_total / p.NT;
+  p.tiles_x = (W + TW - 1) / TW;
+  p.tiles_y = (H + TH - 1) / TH;
+  p.n_tiles = B * p.tiles_x * p.tiles_y;
+  int gx = 1024 / p.grid_y;                   // ~4 workgroups per CU over the whole launch
+  if (gx < 256) gx = 256;
+  if (gx > p.n_tiles) gx = p.n_tiles;
+  p.grid_x = gx;
+  p.lds = (size_t)HP * p.CPG * 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024;
+  return true;
+}
+
+template <typename T, int NT, int CPG>
+void launch_fwd_k(const FwdPlan& p, const void* x, const void* wp, const float* bias, void* z, float* partials, int B,
+                  int H, int W, int Cin, int Cout, hipStream_t st) {
+  conv3x3_mfma_kernel<T, NT, CPG><<<dim3(p.grid_x, p.grid_y), CM_THREADS, p.lds, st>>>(
+      (const T*)x, (const T*)wp, bias, (T*)z, partials, B, H, W, Cin, Cout, p.n_chunks, p.nt_total, p.tiles_x,
+      p.tiles_y, p.n_tiles);
+}
+
+template <typename T, int NT>
+void launch_fwd_cpg(const FwdPlan& p, const void* x, const void* wp, const float* bias, void* z, float* partials,
+                    int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+  switch (p.CPG) {
+    case 1: launch_fwd_k<T, NT, 1>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 2: launch_fwd_k<T, NT, 2>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 3: launch_fwd_k<T, NT, 3>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    default: launch_fwd_k<T, NT, 4>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+  }
+}
+
+template <typename T>
+int run_fwd(const void* x, const void* wp, const float* bias, int B, int H, int W, int Cin, int Cout, void* z,
+            float* stats, void* workspace, hipStream_t st) {
+  FwdPlan p;
+  if (!plan_fwd<T>(B, H, W, Cin, Cout, p)) {
+    mis_set_error("conv3x3_mfma: unsupported shape Cin=%d Cout=%d", Cin, Cout);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  float* partials = stats ? (float*)workspace : nullptr;
+  switch (p.NT) {
+    case 1: launch_fwd_cpg<T, 1>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 2: launch_fwd_cpg<T, 2>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    default: launch_fwd_cpg<T, 4>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+  }
+  MIS_CHECK_LAUNCH("conv3x3_mfma_kernel");
+  if (stats) {
+    launch_reduce_partials(partials, p.grid_x, 2 * Cout, stats, st);
+    MIS_CHECK_LAUNCH("reduce_partials_kernel");
+  }
+  return MIS_OK;
+}
+
+}  // namespace
+
+bool conv3x3_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout) {
+  FwdPlan p;
+  return dtype == MIS_BF16 ? plan_fwd<bf16>(B, H, W, Cin, Cout, p) : plan_fwd<float>(B, H, W, Cin, Cout, p);
+}
+
+size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout) {
+  return align256((size_t)1024 * 2 * Cout * sizeof(float));
+}
+
+size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout) {
+  const int G = dtype == MIS_BF16 ? 8 : 4;
+  const int groups = Cin / G;
+  const int CPG = groups <= 4 ? groups : 4;
+  const int n_chunks = groups <= 4 ? 1 : groups / 4;
+  return (size_t)n_chunks * nsteps_of(CPG) * ((Cout + 15) / 16) * 1024;
+}
+
+int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st) {
+  const int Cin = transposed ? Cw_out : Cw_in, Cout = transposed ? Cw_in : Cw_out;   // conv roles
+  const int G = dtype == MIS_BF16 ? 8 : 4;
+  const int groups = Cin / G;
+  const int CPG = groups <= 4 ? groups : 4;
+  const int n_chunks = groups <= 4 ? 1 : groups / 4;
+  const int nt_total = (Cout + 15) / 16;
+  const int64_t total = (int64_t)n_chunks * nsteps_of(CPG) * nt_total * 64 * G;
+  const int grid = ew_grid(total, 256);
+  if (dtype == MIS_BF16)
+    pack_w3x3_frag_kernel<bf16><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, transposed, CPG, n_chunks, nt_total, (bf16*)out);
+  else
+    pack_w3x3_frag_kernel<float><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, transposed, CPG, n_chunks, nt_total, (float*)out);
+  MIS_CHECK_LAUNCH("pack_w3x3_frag_kernel");
+  return MIS_OK;
+}
+
+int conv3x3_mfma_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
+                     int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
+  if (dtype == MIS_BF16) return run_fwd<bf16>(x, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
+  return run_fwd<float>(x, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
+}
+
+// weight gradient on the matrix cores: not built yet -> the dispatcher uses the vector-ALU kernel
 bool conv3x3_wgrad_mfma_supported(int, int, int, int, int, int) { return false; }
 size_t conv3x3_wgrad_mfma_workspace_bytes(int, int, int, int, int, int) { return 0; }
-int conv3x3_wgrad_mfma(const void*, const void*, int, int, int, int, int, int, float*, void*, hipStream_t) { return MIS_ERR_UNSUPPORTED; }
+int conv3x3_wgrad_mfma(const void*, const void*, int, int, int, int, int, int, float*, void*, hipStream_t) {
+  return MIS_ERR_UNSUPPORTED;
+}

@@ -37,7 +37,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
 
 static inline void launch_reduce_partials(const float* partials, int nblk, int n, float* out, hipStream_t st,
                                           int64_t stride = 0) {
-  reduce_partials_kernel<<<cdiv(n, 256), 256, 0, st>>>(partials, nblk, n, stride ? stride : n, out);
+  reduce_partials_kernel<<<cdiv(n, 32), 256, 0, st>>>(partials, nblk, n, stride ? stride : n, out);
 }
 
 // F provides:  static constexpr int NOUT;

@@ -127,13 +127,13 @@ def profile_summary(peak_hbm_gbs, peak_tflops, steps=1):
 # ---------------------------------------------------------------------------
 # raw ops (no autograd)
 # ---------------------------------------------------------------------------
-def pack_weights(w, dtype, fwd=True, dgrad=False):
+def pack_weights(w, dtype, transposed=False):
+    """float32 [Cout, Cin, 3, 3] -> the library's private operand image (a byte buffer)."""
     Co, Ci = w.shape[0], w.shape[1]
-    wf = torch.empty((9, Co, Ci), dtype=dtype, device=w.device) if fwd else None
-    wd = torch.empty((9, Ci, Co), dtype=dtype, device=w.device) if dgrad else None
-    call("mis_pack_conv3x3_weights", w.data_ptr(), Co, Ci, _DT[dtype],
-         wf.data_ptr() if fwd else None, wd.data_ptr() if dgrad else None, _stream())
-    return wf, wd
+    nbytes = query("mis_conv3x3_packed_weight_bytes", Co, Ci, int(transposed), _DT[dtype])
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    call("mis_pack_conv3x3_weights", w.data_ptr(), Co, Ci, int(transposed), _DT[dtype], out.data_ptr(), _stream())
+    return out
 
 
 def conv3x3_raw(x, w_packed, bias, Cout, want_stats):
@@ -183,7 +183,7 @@ class ConvBnReluFn(torch.autograd.Function):
         if weight.shape != (Cout, Cin, 3, 3):
             raise ValueError(f"weight {tuple(weight.shape)} does not match input channels {Cin}")
         n_pix = B * H * W
-        wf, _ = pack_weights(weight.detach(), x.dtype, fwd=True)
+        wf = pack_weights(weight.detach(), x.dtype)
         z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout, training)
         ss = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         mr = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
@@ -231,7 +231,7 @@ class ConvBnReluFn(torch.autograd.Function):
         dbias = channel_sum_raw(dz) if ctx.has_bias and ctx.needs_input_grad[2] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            _, wd = pack_weights(weight.detach(), x.dtype, fwd=False, dgrad=True)
+            wd = pack_weights(weight.detach(), x.dtype, transposed=True)
             dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
         dw = conv3x3_wgrad_raw(x, dz) if ctx.needs_input_grad[1] else None
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None

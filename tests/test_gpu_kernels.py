@@ -377,3 +377,53 @@ def test_conv1x1(F_, dtype, shape):
     assert rel_err(xd.grad, xo.grad) < tol
     assert rel_err(wd.grad, wo.grad) < 5 * tol
     assert rel_err(bd.grad, bo.grad) < 5 * tol
+
+
+# ---------------------------------------------------------------------------
+# matrix-core conv kernels against the vector-ALU kernels and the oracle
+# ---------------------------------------------------------------------------
+MFMA_SHAPES = [  # B, Cin, Cout, H, W
+    (2, 8, 32, 16, 16), (1, 16, 64, 32, 32), (1, 32, 16, 32, 48), (2, 64, 32, 16, 16), (1, 128, 64, 16, 16),
+    (1, 64, 256, 16, 16), (1, 256, 512, 8, 8), (1, 512, 32, 16, 16), (2, 64, 8, 32, 32), (1, 24, 8, 20, 12),
+    (3, 8, 8, 4, 4), (1, 32, 128, 2, 2), (1, 12, 16, 16, 16), (1, 4, 8, 16, 16), (1, 16, 24, 18, 34)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", MFMA_SHAPES)
+@pytest.mark.parametrize("transposed", [False, True])
+def test_conv3x3_mfma_vs_direct_and_oracle(F_, dtype, shape, transposed):
+    """z = conv(x, W) (+ statistics) for the forward operand and for the data-gradient
+    operand (W^T, taps mirrored), on the matrix-core kernel and the vector-ALU kernel."""
+    from medical_image_segmentation_amd import _lib
+    B, Ci, Co, H, W = shape
+    G = 8 if dtype == torch.bfloat16 else 4
+    if Ci % G or (Ci > 4 * G and Ci % (4 * G)):
+        pytest.skip("shape not taken by the matrix-core kernel in this dtype")
+    x = dg.hash_normalish((B, Ci, H, W), 701)
+    # forward conv Ci->Co uses master weights [Co,Ci,3,3]; the dgrad operand of master weights
+    # [Ci,Co,3,3] also maps Ci->Co channels
+    wm = dg.hash_normalish((Ci, Co, 3, 3) if transposed else (Co, Ci, 3, 3), 702, std=(2.0 / (9 * Ci)) ** 0.5)
+    b = dg.hash_uniform((Co,), 703, -0.1, 0.1)
+    xd = act(x, dtype)
+    wd = T(wm).to(DEV)
+    bd = None if transposed else T(b).to(DEV)
+    outs = []
+    for mode in (0, 1):
+        _lib.call("mis_set_conv_path", mode)
+        try:
+            wp = F_.pack_weights(wd, dtype, transposed=transposed)
+            z, stats = F_.conv3x3_raw(xd, wp, bd, Co, True)
+            torch.cuda.synchronize()
+        finally:
+            _lib.call("mis_set_conv_path", 0)
+        outs.append((z.float().cpu(), stats.cpu()))
+    wq = q(wm, dtype).double()
+    w_eff = wq.flip(2, 3).transpose(0, 1) if transposed else wq
+    zo = torch.nn.functional.conv2d(q(x, dtype).double(), w_eff, None if transposed else T(b).double(), padding=1)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for z, stats in outs:
+        assert rel_err(z, zo) < tol
+        assert rel_err(stats[0], zo.sum(dim=(0, 2, 3))) < 1e-4 + (0 if dtype == torch.float32 else 1e-3)
+        assert rel_err(stats[1], (zo * zo).sum(dim=(0, 2, 3))) < 1e-4 + (0 if dtype == torch.float32 else 1e-3)
+    # the two kernels accumulate the same products in float32: near-identical results
+    assert rel_err(outs[0][0], outs[1][0]) < (2e-6 if dtype == torch.float32 else 8e-3)
