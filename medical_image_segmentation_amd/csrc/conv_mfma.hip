@@ -337,7 +337,10 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
 template <typename T, int NT, int CPG>
 void launch_fwd_k(const FwdPlan& p, const void* x, const void* wp, const float* bias, void* z, float* partials, int B,
                   int H, int W, int Cin, int Cout, hipStream_t st) {
-  conv3x3_mfma_kernel<T, NT, CPG><<<dim3(p.grid_x, p.grid_y), CM_THREADS, p.lds, st>>>(
+  auto kfn = conv3x3_mfma_kernel<T, NT, CPG>;
+  if (p.lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+  kfn<<<dim3(p.grid_x, p.grid_y), CM_THREADS, p.lds, st>>>(
       (const T*)x, (const T*)wp, bias, (T*)z, partials, B, H, W, Cin, Cout, p.n_chunks, p.nt_total, p.tiles_x,
       p.tiles_y, p.n_tiles);
 }
@@ -417,9 +420,281 @@ int conv3x3_mfma_fwd(const void* x, const void* wp, const float* bias, int dtype
   return run_fwd<float>(x, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
 }
 
-// weight gradient on the matrix cores: not built yet -> the dispatcher uses the vector-ALU kernel
-bool conv3x3_wgrad_mfma_supported(int, int, int, int, int, int) { return false; }
-size_t conv3x3_wgrad_mfma_workspace_bytes(int, int, int, int, int, int) { return 0; }
-int conv3x3_wgrad_mfma(const void*, const void*, int, int, int, int, int, int, float*, void*, hipStream_t) {
-  return MIS_ERR_UNSUPPORTED;
+// =====================================================================================
+// Weight gradient on the matrix cores.
+//
+//   dW[tap][co][ci] = sum over pixels p of dz[p][co] * x[p + off(tap)][ci]
+//
+// A GEMM whose K dimension is the pixel index: both operands are "K-major" in a
+// channels-last tensor (a lane needs 8 consecutive PIXELS of one channel), which is exactly
+// what ds_read_b64_tr_b16 delivers from a row-major [pixel][channel] LDS tile: no software
+// transpose.  A workgroup stages a TH x 32 pixel tile of dz and the matching (TH+2) x 34 halo
+// of x, each of its K-steps is one 32-pixel row segment, and the dz fragment of a step is
+// reused by the 9 taps (the x fragment is the same row shifted by the tap).  Workgroups walk
+// tiles grid-stride and keep the 9 x (co-tile x ci-tile) accumulators in registers; at the
+// end each writes its partial to a slab, and a second kernel sums the slabs in a fixed order
+// (bitwise reproducible, no float atomics) into the nn.Conv2d layout [Cout][Cin][3][3].
+//
+// Wave roles (template): WCO x WCI x WK = 4 waves.  Small channel counts: all waves split
+// the rows of a tile (WK = 4) and are summed through LDS at the end; large: waves tile a
+// 64 x 64 (co x ci) block.
+// float32 mode uses v_mfma_f32_16x16x4_f32 with plain 4-byte LDS reads (K-step = 4 pixels).
+//
+// Roofline: min(MFMA, HBM); algorithmic bytes = B*H*W*(Cin+Cout)*sizeof(T) + 36*Cin*Cout.
+namespace {
+
+constexpr int WG_TW = 32;
+
+template <typename T> struct WgT;
+template <> struct WgT<bf16> { static constexpr int TH = 8; };
+template <> struct WgT<float> { static constexpr int TH = 4; };
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int row_elems, int pos0, int c0, int lane) {
+  // 8 pixels (pos0 + 8g .. +7) x 16 channels (c0 ..) -> lane i of group g: channel c0+i, 8 pixels
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const bf16* a0 = tile + (pos0 + 8 * g + q) * row_elems + c0 + 4 * p;
+  const bf16* a1 = a0 + 4 * row_elems;
+  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)a0);
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)a1);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <typename T, int MTO, int NTI, int WCO, int WCI, int WK>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dz,
+                                                                 float* __restrict__ slab, int B, int H, int W,
+                                                                 int Cin, int Cout, int n_ci_blocks, int tiles_x,
+                                                                 int tiles_y, int n_tiles) {
+  static_assert(WCO * WCI * WK == 4, "4 waves");
+  constexpr int G = Mf<T>::G;
+  constexpr int TH = WgT<T>::TH;
+  constexpr int HWW = WG_TW + 2;                 // halo width 34
+  constexpr int PH = (TH + 2) * HWW;             // halo positions
+  constexpr int PZ = TH * WG_TW;                 // dz positions
+  constexpr int CTO = WCO * MTO * 16, CTI = WCI * NTI * 16;
+  constexpr int XV = PH * (CTI / G), ZV = PZ * (CTO / G);
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* xh = reinterpret_cast<T*>(smem);            // [PH][CTI]
+  T* zt = xh + PH * CTI;                         // [PZ][CTO]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wk = wid % WK, wci = (wid / WK) % WCI, wco = wid / (WK * WCI);
+  const int cib = blockIdx.y % n_ci_blocks, cob = blockIdx.y / n_ci_blocks;
+  const int ci0 = cib * CTI, co0 = cob * CTO;
+
+  f32x4 acc[9][MTO][NTI];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int mo = 0; mo < MTO; mo++)
+#pragma unroll
+      for (int ni = 0; ni < NTI; ni++) acc[t][mo][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * WG_TW;
+    __syncthreads();
+    for (int v = tid; v < XV; v += 256) {
+      const int pos = v / (CTI / G), cv = v % (CTI / G);
+      const int gy = y0 - 1 + pos / HWW, gx = x0 - 1 + pos % HWW;
+      const int c = ci0 + cv * G;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cin)
+        val = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + gy) * W + gx) * Cin + c);
+      *reinterpret_cast<uint4*>(xh + pos * CTI + cv * G) = val;
+    }
+    for (int v = tid; v < ZV; v += 256) {
+      const int pos = v / (CTO / G), cv = v % (CTO / G);
+      const int gy = y0 + pos / WG_TW, gx = x0 + pos % WG_TW;
+      const int c = co0 + cv * G;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (gy < H && gx < W && c < Cout)
+        val = *reinterpret_cast<const uint4*>(dz + (((int64_t)b * H + gy) * W + gx) * Cout + c);
+      *reinterpret_cast<uint4*>(zt + pos * CTO + cv * G) = val;
+    }
+    __syncthreads();
+
+    for (int r = wk; r < TH; r += WK) {
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 a[MTO];
+#pragma unroll
+        for (int mo = 0; mo < MTO; mo++) a[mo] = tr_frag(zt, CTO, r * WG_TW, (wco * MTO + mo) * 16, lane);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+#pragma unroll
+          for (int ni = 0; ni < NTI; ni++) {
+            const bf16x8 bq = tr_frag(xh, CTI, (r + t / 3) * HWW + (t % 3), (wci * NTI + ni) * 16, lane);
+#pragma unroll
+            for (int mo = 0; mo < MTO; mo++)
+              acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mo], bq, acc[t][mo][ni], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int kk = 0; kk < WG_TW / 4; kk++) {
+          const int px = 4 * kk + (lane >> 4);
+          float a[MTO];
+#pragma unroll
+          for (int mo = 0; mo < MTO; mo++) a[mo] = zt[(r * WG_TW + px) * CTO + (wco * MTO + mo) * 16 + (lane & 15)];
+#pragma unroll
+          for (int t = 0; t < 9; t++) {
+#pragma unroll
+            for (int ni = 0; ni < NTI; ni++) {
+              const float bq = xh[((r + t / 3) * HWW + (t % 3) + px) * CTI + (wci * NTI + ni) * 16 + (lane & 15)];
+#pragma unroll
+              for (int mo = 0; mo < MTO; mo++)
+                acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo], bq, acc[t][mo][ni], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // sum the WK row-split waves through LDS (wave wk=0 of each (wco,wci) keeps the total)
+  if constexpr (WK > 1) {
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    for (int src = 1; src < WK; src++) {
+      __syncthreads();
+      if (wk == src) {
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+          for (int mo = 0; mo < MTO; mo++)
+#pragma unroll
+            for (int ni = 0; ni < NTI; ni++) red[((t * MTO + mo) * NTI + ni) * 64 + lane] = acc[t][mo][ni];
+      }
+      __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+          for (int mo = 0; mo < MTO; mo++)
+#pragma unroll
+            for (int ni = 0; ni < NTI; ni++) acc[t][mo][ni] += red[((t * MTO + mo) * NTI + ni) * 64 + lane];
+      }
+    }
+  }
+  if (wk == 0) {
+    // lane: 4 consecutive co (rows 4*(lane>>4)+r) of one ci (col lane&15); slab [split][tap][ci][co]
+    float* sl = slab + (int64_t)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int mo = 0; mo < MTO; mo++)
+#pragma unroll
+        for (int ni = 0; ni < NTI; ni++) {
+          const int co = co0 + (wco * MTO + mo) * 16 + 4 * (lane >> 4);
+          const int ci = ci0 + (wci * NTI + ni) * 16 + (lane & 15);
+          if (co < Cout && ci < Cin)
+            *reinterpret_cast<f32x4*>(sl + ((int64_t)t * Cin + ci) * Cout + co) = acc[t][mo][ni];
+        }
+  }
+}
+
+// dw[co][ci][tap] = sum_s slab[s][tap][ci][co]; 8 row lanes x 32 columns per workgroup, fixed order.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cin, int Cout,
+                                    float* __restrict__ dw) {
+  __shared__ double red[8][32];
+  const int n = 9 * Cin * Cout;
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
+  double s = 0.0;
+  if (j < n)
+    for (int i = r; i < nsplit; i += 8) s += (double)slab[(int64_t)i * n + j];
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0 && j < n) {
+    double t = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; k++) t += red[k][c];
+    const int co = j % Cout, ci = (j / Cout) % Cin, tap = j / (Cout * Cin);
+    dw[((int64_t)co * Cin + ci) * 9 + tap] = (float)t;
+  }
+}
+
+struct WgPlan {
+  int cfg;          // 0: 1x1 tiles, K-split waves; 1: 2x1 (co 32 x ci 16); 2: 1x2; 3: 2x2 K-split; 4: 64x64 block
+  int CTO, CTI, n_co_blocks, n_ci_blocks, tiles_x, tiles_y, n_tiles, nsplit;
+  size_t lds;
+};
+
+template <typename T>
+bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p) {
+  constexpr int G = Mf<T>::G;
+  constexpr int TH = WgT<T>::TH;
+  if (Cin % G != 0 || Cout % G != 0) return false;
+  if (Cout >= 64 && Cin >= 64) { p.cfg = 4; p.CTO = 64; p.CTI = 64; }
+  else if (Cout > 16 && Cin > 16) { p.cfg = 3; p.CTO = 32; p.CTI = 32; }
+  else if (Cout > 16) { p.cfg = 1; p.CTO = 32; p.CTI = 16; }
+  else if (Cin > 16) { p.cfg = 2; p.CTO = 16; p.CTI = 32; }
+  else { p.cfg = 0; p.CTO = 16; p.CTI = 16; }
+  p.n_co_blocks = (Cout + p.CTO - 1) / p.CTO;
+  p.n_ci_blocks = (Cin + p.CTI - 1) / p.CTI;
+  p.tiles_x = (W + WG_TW - 1) / WG_TW;
+  p.tiles_y = (H + TH - 1) / TH;
+  p.n_tiles = B * p.tiles_x * p.tiles_y;
+  const int nout = p.n_co_blocks * p.n_ci_blocks;
+  int ns = 1024 / nout;
+  if (ns < 1) ns = 1;
+  if (ns > p.n_tiles) ns = p.n_tiles;
+  if (ns > 1024) ns = 1024;
+  p.nsplit = ns;
+  const size_t tiles = ((size_t)(TH + 2) * (WG_TW + 2) * p.CTI + (size_t)TH * WG_TW * p.CTO) * sizeof(T);
+  const size_t redb = (p.cfg == 4) ? 0 : (size_t)9 * (p.CTO / 16) * (p.CTI / 16) * 64 * 16;
+  p.lds = tiles > redb ? tiles : redb;
+  return true;
+}
+
+template <typename T>
+int run_wgrad(const void* x, const void* dz, int B, int H, int W, int Cin, int Cout, float* dw, void* workspace,
+              hipStream_t st) {
+  WgPlan p;
+  if (!plan_wgrad<T>(B, H, W, Cin, Cout, p)) {
+    mis_set_error("conv3x3_wgrad_mfma: unsupported shape Cin=%d Cout=%d", Cin, Cout);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  float* slab = (float*)workspace;
+  dim3 grid(p.nsplit, p.n_co_blocks * p.n_ci_blocks);
+#define WG_LAUNCH(MTO, NTI, WCO, WCI, WK)                                                                  \
+  {                                                                                                        \
+    auto kfn = conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK>;                                       \
+    if (p.lds > 48 * 1024)                                                                                 \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
+    kfn<<<grid, 256, p.lds, st>>>((const T*)x, (const T*)dz, slab, B, H, W, Cin, Cout, p.n_ci_blocks,      \
+                                  p.tiles_x, p.tiles_y, p.n_tiles);                                        \
+  }
+  switch (p.cfg) {
+    case 0: WG_LAUNCH(1, 1, 1, 1, 4); break;
+    case 1: WG_LAUNCH(2, 1, 1, 1, 4); break;
+    case 2: WG_LAUNCH(1, 2, 1, 1, 4); break;
+    case 3: WG_LAUNCH(2, 2, 1, 1, 4); break;
+    default: WG_LAUNCH(2, 2, 2, 2, 1); break;
+  }
+#undef WG_LAUNCH
+  MIS_CHECK_LAUNCH("conv3x3_wgrad_mfma_kernel");
+  wgrad_reduce_kernel<<<cdiv(9 * Cin * Cout, 32), 256, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
+  MIS_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return MIS_OK;
+}
+
+}  // namespace
+
+bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout) {
+  WgPlan p;
+  return dtype == MIS_BF16 ? plan_wgrad<bf16>(B, H, W, Cin, Cout, p) : plan_wgrad<float>(B, H, W, Cin, Cout, p);
+}
+
+size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout) {
+  WgPlan p;
+  const bool ok = dtype == MIS_BF16 ? plan_wgrad<bf16>(B, H, W, Cin, Cout, p) : plan_wgrad<float>(B, H, W, Cin, Cout, p);
+  if (!ok) return 0;
+  return align256((size_t)p.nsplit * 9 * Cin * Cout * sizeof(float));
+}
+
+int conv3x3_wgrad_mfma(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
+                       void* workspace, hipStream_t st) {
+  if (dtype == MIS_BF16) return run_wgrad<bf16>(x, dz, B, H, W, Cin, Cout, dw, workspace, st);
+  return run_wgrad<float>(x, dz, B, H, W, Cin, Cout, dw, workspace, st);
 }

@@ -427,3 +427,34 @@ def test_conv3x3_mfma_vs_direct_and_oracle(F_, dtype, shape, transposed):
         assert rel_err(stats[1], (zo * zo).sum(dim=(0, 2, 3))) < 1e-4 + (0 if dtype == torch.float32 else 1e-3)
     # the two kernels accumulate the same products in float32: near-identical results
     assert rel_err(outs[0][0], outs[1][0]) < (2e-6 if dtype == torch.float32 else 8e-3)
+
+
+WGRAD_SHAPES = [  # B, Cin, Cout, H, W
+    (2, 8, 32, 16, 32), (1, 16, 64, 32, 32), (1, 32, 16, 32, 64), (2, 64, 32, 16, 16), (1, 128, 64, 16, 32),
+    (1, 64, 256, 16, 16), (1, 256, 512, 8, 8), (1, 512, 32, 16, 16), (2, 64, 8, 32, 32), (1, 24, 8, 20, 12),
+    (3, 8, 8, 4, 4), (1, 32, 128, 2, 2), (1, 8, 16, 9, 33), (2, 128, 8, 16, 16), (1, 16, 24, 18, 34)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_conv3x3_wgrad_mfma_vs_direct_and_oracle(F_, dtype, shape):
+    from medical_image_segmentation_amd import _lib
+    B, Ci, Co, H, W = shape
+    x = np.maximum(dg.hash_normalish((B, Ci, H, W), 801), 0)
+    gz = dg.hash_normalish((B, Co, H, W), 802)
+    xd, gd = act(x, dtype), act(gz, dtype)
+    outs = []
+    for mode in (0, 1):
+        _lib.call("mis_set_conv_path", mode)
+        try:
+            outs.append(F_.conv3x3_wgrad_raw(xd, gd).cpu())
+            torch.cuda.synchronize()
+        finally:
+            _lib.call("mis_set_conv_path", 0)
+    xo = q(x, dtype).double()
+    wo = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xo, wo, None, padding=1).backward(q(gz, dtype).double())
+    for dw in outs:
+        assert dw.shape == (Co, Ci, 3, 3)
+        assert rel_err(dw, wo.grad) < 2e-5      # inputs are exact in both dtypes; float32 accumulation
+    assert rel_err(outs[0], outs[1]) < 2e-5
