@@ -11,22 +11,29 @@
 #include "vec.h"
 #include "reduce.h"
 
-// 256 threads = 8 row lanes x 32 columns: coalesced 128-byte row reads, double accumulation,
-// fixed combination order (bitwise reproducible).
-__global__ void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int n, int64_t stride,
-                                       float* __restrict__ out) {
-  __shared__ double red[8][32];
+// 1024 threads = 32 row lanes x 32 columns: coalesced 128-byte row reads, 4 independent loads
+// in flight per thread, double accumulation, fixed combination order (bitwise reproducible).
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int n,
+                                                               int64_t stride, float* __restrict__ out) {
+  __shared__ double red[32][33];
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + c;
   double s = 0.0;
-  if (j < n)
-    for (int i = r; i < nblk; i += 8) s += (double)partials[(int64_t)i * stride + j];
+  if (j < n) {
+    int i = r;
+    for (; i + 96 < nblk; i += 128) {
+      const float a0 = partials[(int64_t)i * stride + j], a1 = partials[(int64_t)(i + 32) * stride + j];
+      const float a2 = partials[(int64_t)(i + 64) * stride + j], a3 = partials[(int64_t)(i + 96) * stride + j];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; i < nblk; i += 32) s += (double)partials[(int64_t)i * stride + j];
+  }
   red[r][c] = s;
   __syncthreads();
   if (r == 0 && j < n) {
-    double t = red[0][c];
+    double t = 0.0;
 #pragma unroll
-    for (int k = 1; k < 8; k++) t += red[k][c];
+    for (int k = 0; k < 32; k++) t += red[k][c];
     out[j] = (float)t;
   }
 }

@@ -326,7 +326,7 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
   p.tiles_x = (W + TW - 1) / TW;
   p.tiles_y = (H + TH - 1) / TH;
   p.n_tiles = B * p.tiles_x * p.tiles_y;
-  int gx = 1024 / p.grid_y;                   // ~4 workgroups per CU over the whole launch
+  int gx = 768 / p.grid_y;                    // ~3 workgroups per CU over the whole launch
   if (gx < 256) gx = 256;
   if (gx > p.n_tiles) gx = p.n_tiles;
   p.grid_x = gx;
@@ -449,14 +449,26 @@ template <typename T> struct WgT;
 template <> struct WgT<bf16> { static constexpr int TH = 8; };
 template <> struct WgT<float> { static constexpr int TH = 4; };
 
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int row_elems, int pos0, int c0, int lane) {
-  // 8 pixels (pos0 + 8g .. +7) x 16 channels (c0 ..) -> lane i of group g: channel c0+i, 8 pixels
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const bf16* a0 = tile + (pos0 + 8 * g + q) * row_elems + c0 + 4 * p;
-  const bf16* a1 = a0 + 4 * row_elems;
+// LDS tiles are [position][CT channels] with rows padded to an odd multiple of 32 bytes, so
+// that the 8 consecutive positions one half-wave transposed read touches fall on 8 distinct
+// 32-byte bank windows (conflict-free) while every address stays "per-lane base + uniform
+// offset" (tap shifts fold into the instruction's immediate offset).
+constexpr int padded_row_bytes(int row_bytes) { return ((row_bytes / 32) % 2 == 0 && row_bytes > 32) ? row_bytes + 32 : row_bytes; }
+
+// K index of the MFMA (k = 8g + 4h + q; g = lane group, h = which of the two transposed
+// reads, q = row inside the read) -> pixel offset inside the 32-pixel step.  Chosen so that
+// the two groups of a half-wave read 8 CONSECUTIVE pixels.
+__device__ __forceinline__ int k_pixel(int g, int h, int q) { return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + q; }
+
+// 32 pixels x 16 channels -> lane i of group g: channel c0+i, its 8 k values.  `lane_off` is
+// the lane's byte offset (k_pixel(g,0,q)*RSP + 8p), `uni_off` the wave-uniform byte offset of
+// (first position, first channel); the second read is 8 positions further.
+template <int RSP>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int lane_off, int uni_off) {
   typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+  const unsigned char* a0 = tile + lane_off + uni_off;
   bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)a0);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)a1);
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(a0 + 8 * RSP));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
@@ -472,11 +484,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
   constexpr int PH = (TH + 2) * HWW;             // halo positions
   constexpr int PZ = TH * WG_TW;                 // dz positions
   constexpr int CTO = WCO * MTO * 16, CTI = WCI * NTI * 16;
-  constexpr int XV = PH * (CTI / G), ZV = PZ * (CTO / G);
+  constexpr int XVP = CTI / G, ZVP = CTO / G;    // 16-byte vectors per position
+  constexpr int XV = PH * XVP, ZV = PZ * ZVP;
+  constexpr int XIT = (XV + 255) / 256, ZIT = (ZV + 255) / 256;
+  constexpr int RSX = padded_row_bytes(CTI * (int)sizeof(T)), RSZ = padded_row_bytes(CTO * (int)sizeof(T));
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* xh = reinterpret_cast<T*>(smem);            // [PH][CTI]
-  T* zt = xh + PH * CTI;                         // [PZ][CTO]
+  unsigned char* xh = smem;                      // [PH] rows of RSX bytes (CTI channels + pad)
+  unsigned char* zt = smem + PH * RSX;           // [PZ] rows of RSZ bytes
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid % WK, wci = (wid / WK) % WCI, wco = wid / (WK * WCI);
@@ -491,40 +506,68 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
 #pragma unroll
       for (int ni = 0; ni < NTI; ni++) acc[t][mo][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int y0 = ty * TH, x0 = tx * WG_TW;
+  uint4 xr[XIT], zr[ZIT];
+#define WG_LOAD(TILE)                                                                                   \
+  {                                                                                                     \
+    const int t_ = (TILE);                                                                              \
+    const int tx_ = t_ % tiles_x, ty_ = (t_ / tiles_x) % tiles_y, b_ = t_ / (tiles_x * tiles_y);        \
+    const int y0_ = ty_ * TH, x0_ = tx_ * WG_TW;                                                        \
+    _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                   \
+      const int v = tid + i * 256;                                                                      \
+      const int pos = v / XVP, cv = v % XVP;                                                            \
+      const int gy = y0_ - 1 + pos / HWW, gx = x0_ - 1 + pos % HWW;                                     \
+      const int c = ci0 + cv * G;                                                                       \
+      const bool ok = (v < XV) && gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cin;                    \
+      xr[i] = ok ? *reinterpret_cast<const uint4*>(x + (((int64_t)b_ * H + gy) * W + gx) * Cin + c)     \
+                 : make_uint4(0, 0, 0, 0);                                                              \
+    }                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < ZIT; i++) {                                                   \
+      const int v = tid + i * 256;                                                                      \
+      const int pos = v / ZVP, cv = v % ZVP;                                                            \
+      const int gy = y0_ + pos / WG_TW, gx = x0_ + pos % WG_TW;                                         \
+      const int c = co0 + cv * G;                                                                       \
+      const bool ok = (v < ZV) && gy < H && gx < W && c < Cout;                                         \
+      zr[i] = ok ? *reinterpret_cast<const uint4*>(dz + (((int64_t)b_ * H + gy) * W + gx) * Cout + c)   \
+                 : make_uint4(0, 0, 0, 0);                                                              \
+    }                                                                                                   \
+  }
+#define WG_STORE()                                                                                      \
+  {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                   \
+      const int v = tid + i * 256;                                                                      \
+      const int pos = v / XVP, cv = v % XVP;                                                            \
+      if (v < XV) *reinterpret_cast<uint4*>(xh + pos * RSX + cv * 16) = xr[i];                          \
+    }                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < ZIT; i++) {                                                   \
+      const int v = tid + i * 256;                                                                      \
+      const int pos = v / ZVP, cv = v % ZVP;                                                            \
+      if (v < ZV) *reinterpret_cast<uint4*>(zt + pos * RSZ + cv * 16) = zr[i];                          \
+    }                                                                                                   \
+  }
+
+  // per-lane byte offsets of the transposed reads (bf16) inside the two tiles
+  const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  const int offx = k_pixel(lg, 0, lq) * RSX + 8 * lp + wci * NTI * 32;
+  const int offz = k_pixel(lg, 0, lq) * RSZ + 8 * lp + wco * MTO * 32;
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) WG_LOAD(tile)
+  for (; tile < n_tiles; tile += gridDim.x) {
     __syncthreads();
-    for (int v = tid; v < XV; v += 256) {
-      const int pos = v / (CTI / G), cv = v % (CTI / G);
-      const int gy = y0 - 1 + pos / HWW, gx = x0 - 1 + pos % HWW;
-      const int c = ci0 + cv * G;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cin)
-        val = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + gy) * W + gx) * Cin + c);
-      *reinterpret_cast<uint4*>(xh + pos * CTI + cv * G) = val;
-    }
-    for (int v = tid; v < ZV; v += 256) {
-      const int pos = v / (CTO / G), cv = v % (CTO / G);
-      const int gy = y0 + pos / WG_TW, gx = x0 + pos % WG_TW;
-      const int c = co0 + cv * G;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (gy < H && gx < W && c < Cout)
-        val = *reinterpret_cast<const uint4*>(dz + (((int64_t)b * H + gy) * W + gx) * Cout + c);
-      *reinterpret_cast<uint4*>(zt + pos * CTO + cv * G) = val;
-    }
+    WG_STORE()
     __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) WG_LOAD(tile + gridDim.x)
 
     for (int r = wk; r < TH; r += WK) {
       if constexpr (sizeof(T) == 2) {
         bf16x8 a[MTO];
 #pragma unroll
-        for (int mo = 0; mo < MTO; mo++) a[mo] = tr_frag(zt, CTO, r * WG_TW, (wco * MTO + mo) * 16, lane);
+        for (int mo = 0; mo < MTO; mo++) a[mo] = tr_frag<RSZ>(zt, offz, r * WG_TW * RSZ + mo * 32);
 #pragma unroll
         for (int t = 0; t < 9; t++) {
 #pragma unroll
           for (int ni = 0; ni < NTI; ni++) {
-            const bf16x8 bq = tr_frag(xh, CTI, (r + t / 3) * HWW + (t % 3), (wci * NTI + ni) * 16, lane);
+            const bf16x8 bq = tr_frag<RSX>(xh, offx, (r * HWW + (t / 3) * HWW + (t % 3)) * RSX + ni * 32);
 #pragma unroll
             for (int mo = 0; mo < MTO; mo++)
               acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mo], bq, acc[t][mo][ni], 0, 0, 0);
@@ -536,12 +579,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
           const int px = 4 * kk + (lane >> 4);
           float a[MTO];
 #pragma unroll
-          for (int mo = 0; mo < MTO; mo++) a[mo] = zt[(r * WG_TW + px) * CTO + (wco * MTO + mo) * 16 + (lane & 15)];
+          for (int mo = 0; mo < MTO; mo++) {
+            const int pos = r * WG_TW + px, c = (wco * MTO + mo) * 16 + (lane & 15);
+            a[mo] = *reinterpret_cast<const float*>(zt + pos * RSZ + c * 4);
+          }
 #pragma unroll
           for (int t = 0; t < 9; t++) {
 #pragma unroll
             for (int ni = 0; ni < NTI; ni++) {
-              const float bq = xh[((r + t / 3) * HWW + (t % 3) + px) * CTI + (wci * NTI + ni) * 16 + (lane & 15)];
+              const int pos = (r + t / 3) * HWW + (t % 3) + px, c = (wci * NTI + ni) * 16 + (lane & 15);
+              const float bq = *reinterpret_cast<const float*>(xh + pos * RSX + c * 4);
 #pragma unroll
               for (int mo = 0; mo < MTO; mo++)
                 acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo], bq, acc[t][mo][ni], 0, 0, 0);
@@ -551,6 +598,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
       }
     }
   }
+#undef WG_LOAD
+#undef WG_STORE
 
   // sum the WK row-split waves through LDS (wave wk=0 of each (wco,wci) keeps the total)
   if constexpr (WK > 1) {
@@ -593,22 +642,29 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
   }
 }
 
-// dw[co][ci][tap] = sum_s slab[s][tap][ci][co]; 8 row lanes x 32 columns per workgroup, fixed order.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cin, int Cout,
-                                    float* __restrict__ dw) {
-  __shared__ double red[8][32];
+// dw[co][ci][tap] = sum_s slab[s][tap][ci][co]; 32 row lanes x 32 columns per workgroup, fixed order.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cin,
+                                                            int Cout, float* __restrict__ dw) {
+  __shared__ double red[32][33];
   const int n = 9 * Cin * Cout;
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + c;
   double s = 0.0;
-  if (j < n)
-    for (int i = r; i < nsplit; i += 8) s += (double)slab[(int64_t)i * n + j];
+  if (j < n) {
+    int i = r;
+    for (; i + 96 < nsplit; i += 128) {
+      const float a0 = slab[(int64_t)i * n + j], a1 = slab[(int64_t)(i + 32) * n + j];
+      const float a2 = slab[(int64_t)(i + 64) * n + j], a3 = slab[(int64_t)(i + 96) * n + j];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; i < nsplit; i += 32) s += (double)slab[(int64_t)i * n + j];
+  }
   red[r][c] = s;
   __syncthreads();
   if (r == 0 && j < n) {
-    double t = red[0][c];
+    double t = 0.0;
 #pragma unroll
-    for (int k = 1; k < 8; k++) t += red[k][c];
+    for (int k = 0; k < 32; k++) t += red[k][c];
     const int co = j % Cout, ci = (j / Cout) % Cin, tap = j / (Cout * Cin);
     dw[((int64_t)co * Cin + ci) * 9 + tap] = (float)t;
   }
@@ -641,7 +697,8 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p) {
   if (ns > p.n_tiles) ns = p.n_tiles;
   if (ns > 1024) ns = 1024;
   p.nsplit = ns;
-  const size_t tiles = ((size_t)(TH + 2) * (WG_TW + 2) * p.CTI + (size_t)TH * WG_TW * p.CTO) * sizeof(T);
+  const size_t tiles = (size_t)(TH + 2) * (WG_TW + 2) * padded_row_bytes(p.CTI * (int)sizeof(T)) +
+                       (size_t)TH * WG_TW * padded_row_bytes(p.CTO * (int)sizeof(T));
   const size_t redb = (p.cfg == 4) ? 0 : (size_t)9 * (p.CTO / 16) * (p.CTI / 16) * 64 * 16;
   p.lds = tiles > redb ? tiles : redb;
   return true;
@@ -674,7 +731,7 @@ int run_wgrad(const void* x, const void* dz, int B, int H, int W, int Cin, int C
   }
 #undef WG_LAUNCH
   MIS_CHECK_LAUNCH("conv3x3_wgrad_mfma_kernel");
-  wgrad_reduce_kernel<<<cdiv(9 * Cin * Cout, 32), 256, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
+  wgrad_reduce_kernel<<<cdiv(9 * Cin * Cout, 32), 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
   MIS_CHECK_LAUNCH("wgrad_reduce_kernel");
   return MIS_OK;
 }

@@ -11,7 +11,7 @@
 #include "vec.h"
 
 constexpr int RED_THREADS = 256;
-constexpr int RED_MAX_BLOCKS = 1024;
+constexpr int RED_MAX_BLOCKS = 512;
 
 struct RedPlan {
   int CV, PR, nblk;
@@ -37,7 +37,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
 
 static inline void launch_reduce_partials(const float* partials, int nblk, int n, float* out, hipStream_t st,
                                           int64_t stride = 0) {
-  reduce_partials_kernel<<<cdiv(n, 32), 256, 0, st>>>(partials, nblk, n, stride ? stride : n, out);
+  reduce_partials_kernel<<<cdiv(n, 32), 1024, 0, st>>>(partials, nblk, n, stride ? stride : n, out);
 }
 
 // F provides:  static constexpr int NOUT;
