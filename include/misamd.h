@@ -158,14 +158,16 @@ int mis_bn_relu_apply(const void* z, int dtype, int64_t n_pix, int C, const floa
 /* z (y = xhat*gamma + beta > 0), so the activation itself is not an input.       */
 /* Pass 1 reduces  sums[0][c] = sum dy, sums[1][c] = sum dy*xhat  with             */
 /*   dy = da*[y>0], xhat = (z-mean)*rstd;  dbeta = sums[0], dgamma = sums[1].      */
-/* Pass 2 writes  dz = gamma*rstd*(dy - sums0/n - xhat*sums1/n).                    */
+/* Pass 2 writes  dz = gamma*rstd*(dy - sums0/n - xhat*sums1/n)  and, when dbias is */
+/* not NULL (needs the workspace), dbias[c] = sum over pixels of the stored dz —    */
+/* the gradient of the conv bias that feeds this BatchNorm.                         */
 size_t mis_bn_relu_bwd_workspace_bytes(int64_t n_pix, int C);
 int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_pix, int C,
                            const float* mean_rstd, const float* gamma, const float* beta,
                            float* sums, void* workspace, mis_stream_t stream);
 int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, int C,
                        const float* mean_rstd, const float* gamma, const float* beta, const float* sums,
-                       void* dz, mis_stream_t stream);
+                       void* dz, float* dbias, void* workspace, mis_stream_t stream);
 /* Per-channel sum over pixels of a channels-last tensor (conv bias gradient).   */
 size_t mis_channel_sum_workspace_bytes(int64_t n_pix, int C);
 int mis_channel_sum(const void* x, int dtype, int64_t n_pix, int C, float* out, void* workspace,

@@ -44,7 +44,7 @@ PROTOTYPES = {
     "mis_bn_relu_apply": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "mis_bn_relu_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_channel_sum_workspace_bytes": (_sz, [_i64, _i]),
     "mis_channel_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "mis_conv1x1_fwd": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),

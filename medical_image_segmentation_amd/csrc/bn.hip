@@ -130,14 +130,19 @@ struct ChannelSum {
   }
 };
 
+// dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)).  When `dz_partials` is given the grid is
+// sized so that a thread always works on the same channel vector (grid*256 is a multiple of
+// C/V): it then also accumulates sum(dz) per channel — the conv-bias gradient — from the
+// values it stores, and the block writes one partial row [C].
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __restrict__ z, const T* __restrict__ da,
                                                                     T* __restrict__ dz, int64_t n_vec, int C,
                                                                     float inv_n, const float* __restrict__ mean_rstd,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
-                                                                    const float* __restrict__ sums) {
-  extern __shared__ float prm[];   // [6][C]: mean, rstd, gamma, beta, sum_dy/n, sum_dy_xhat/n
+                                                                    const float* __restrict__ sums,
+                                                                    float* __restrict__ dz_partials) {
+  extern __shared__ float prm[];   // [7][C]: mean, rstd, gamma, beta, sum_dy/n, sum_dy_xhat/n, spare; then [256][V]
   for (int i = threadIdx.x; i < C; i += EW_THREADS) {
     prm[i] = mean_rstd[i];
     prm[C + i] = mean_rstd[C + i];
@@ -145,9 +150,13 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
     prm[3 * C + i] = beta[i];
     prm[4 * C + i] = sums[i] * inv_n;
     prm[5 * C + i] = sums[C + i] * inv_n;
+    prm[6 * C + i] = 0.f;
   }
   __syncthreads();
   const int CV = C / V;
+  float bsum[V];
+#pragma unroll
+  for (int k = 0; k < V; k++) bsum[k] = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS) {
     const int c0 = (int)(i % CV) * V;
     float zv[V], gv[V], o[V];
@@ -160,8 +169,23 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
       const float y = xh * prm[2 * C + c] + prm[3 * C + c];
       const float dy = (y > 0.f) ? gv[k] : 0.f;
       o[k] = prm[2 * C + c] * prm[C + c] * (dy - prm[4 * C + c] - xh * prm[5 * C + c]);
+      bsum[k] += to_f32(from_f32<T>(o[k]));
     }
     vstore<T, V>(dz + i * V, o);
+  }
+  if (dz_partials) {
+    // fixed-order block reduction: thread t holds channel vector (blockIdx*256 + t) % CV
+    float* red = prm + 7 * C;                  // [256][V]
+#pragma unroll
+    for (int k = 0; k < V; k++) red[threadIdx.x * V + k] = bsum[k];
+    __syncthreads();
+    const int base = (int)(((int64_t)blockIdx.x * EW_THREADS) % CV);
+    for (int j = threadIdx.x; j < C; j += EW_THREADS) {
+      const int cv = j / V, k = j % V;
+      float acc = 0.f;
+      for (int t = (cv - base + CV) % CV; t < EW_THREADS; t += CV) acc += red[t * V + k];
+      dz_partials[(int64_t)blockIdx.x * C + j] = acc;
+    }
   }
 }
 
@@ -193,17 +217,32 @@ int bwd_reduce_t(const void* z, const void* da, int64_t n_pix, int C, const floa
 
 template <typename T>
 int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, const float* mean_rstd,
-             const float* gamma, const float* beta, const float* sums, hipStream_t st) {
+             const float* gamma, const float* beta, const float* sums, float* dbias, void* ws, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = n_pix * C;
-  const size_t lds = 6 * (size_t)C * sizeof(float);
+  const size_t lds = (7 * (size_t)C + (size_t)EW_THREADS * N) * sizeof(float);
   const float inv_n = (float)(1.0 / (double)n_pix);
-  if (pick_vec<T>(C, z, da, dz) == N)
-    bn_relu_bwd_dz_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>(
-        (const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n, mean_rstd, gamma, beta, sums);
+  const bool vec = pick_vec<T>(C, z, da, dz) == N;
+  const int V = vec ? N : 1;
+  const int CV = C / V;
+  int grid = ew_grid(n / V, EW_THREADS);
+  float* partials = nullptr;
+  if (dbias) {
+    // grid*256 must be a multiple of CV so that a thread keeps one channel vector
+    int g = 1;
+    while ((int64_t)g * EW_THREADS % CV != 0) g++;        // smallest grid unit (CV <= 256*g)
+    grid = (grid / g) * g;
+    if (grid < g) grid = g;
+    if (grid > 1024) grid = (1024 / g) * g > 0 ? (1024 / g) * g : g;
+    partials = (float*)ws;
+  }
+  if (vec)
+    bn_relu_bwd_dz_kernel<T, N><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n,
+                                                                 mean_rstd, gamma, beta, sums, partials);
   else
-    bn_relu_bwd_dz_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>(
-        (const T*)z, (const T*)da, (T*)dz, n, C, inv_n, mean_rstd, gamma, beta, sums);
+    bn_relu_bwd_dz_kernel<T, 1><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n, C, inv_n,
+                                                                 mean_rstd, gamma, beta, sums, partials);
+  if (dbias) launch_reduce_partials(partials, grid, C, dbias, st);
   return 0;
 }
 
@@ -256,7 +295,10 @@ int mis_bn_relu_apply(const void* z, int dtype, int64_t n_pix, int C, const floa
   return MIS_OK;
 }
 
-size_t mis_bn_relu_bwd_workspace_bytes(int64_t n_pix, int C) { return red_workspace_bytes(2, C); }
+size_t mis_bn_relu_bwd_workspace_bytes(int64_t n_pix, int C) {
+  const size_t a = red_workspace_bytes(2, C), b = align256((size_t)1024 * C * sizeof(float));
+  return a > b ? a : b;
+}
 
 int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
                            const float* gamma, const float* beta, float* sums, void* workspace, mis_stream_t stream) {
@@ -274,11 +316,15 @@ int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_p
 }
 
 int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
-                       const float* gamma, const float* beta, const float* sums, void* dz, mis_stream_t stream) {
+                       const float* gamma, const float* beta, const float* sums, void* dz, float* dbias,
+                       void* workspace, mis_stream_t stream) {
   MIS_REQUIRE(z && da && mean_rstd && gamma && beta && sums && dz, "bn_relu_bwd_dz: null pointer");
   MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_dz: bad shape");
-  if (dtype == MIS_F32) bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) bwd_dz_t<bf16>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, (hipStream_t)stream);
+  MIS_REQUIRE(!dbias || workspace, "bn_relu_bwd_dz: dbias requested without a workspace");
+  if (dtype == MIS_F32)
+    bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream);
+  else if (dtype == MIS_BF16)
+    bwd_dz_t<bf16>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream);
   else MIS_REQUIRE(false, "bn_relu_bwd_dz: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("bn_relu_bwd_dz_kernel");
   return MIS_OK;

@@ -200,17 +200,22 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_fwd_kernel(const T* __rest
   }
 }
 
-// Backward of the 1x1 conv: grid.y = Cin / V chunks.  Each thread: dx for its chunk, and
-// block partials of dW[:, chunk] (+ dbias in chunk 0).
+// Backward of the 1x1 conv.  Thread = (pixel, channel vector): consecutive lanes take the
+// consecutive channel vectors of a pixel, then the next pixel, so x / dx accesses of a wave are
+// contiguous.  Each thread writes its dx vector and accumulates dW[:, its channels] (and dbias
+// on the cv==0 lanes); the block reduces in a fixed order through LDS and writes one partial
+// row [CO*Cin + CO].  Requires 256 % (Cin/V) == 0 (a thread keeps its channel vector).
 template <typename T, int V, int CO>
 __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  const float* __restrict__ w, T* __restrict__ dx,
                                                                  float* __restrict__ partials, int64_t n_pix, int Cin,
                                                                  int64_t pix_per_blk) {
-  // partials layout: [gridDim.x][CO*Cin + CO]
-  __shared__ float red[(CO * V + CO) * (CD_THREADS / 64)];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int c0 = blockIdx.y * V;
+  extern __shared__ float red[];                 // [256][CO*V + CO]
+  constexpr int NR = CO * V + CO;
+  const int tid = threadIdx.x;
+  const int CV = Cin / V, PR = CD_THREADS / CV;
+  const int cv = tid % CV, pr = tid / CV;
+  const int c0 = cv * V;
   float wr[CO][V];
 #pragma unroll
   for (int j = 0; j < CO; j++)
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_blk;
   int64_t p1 = p0 + pix_per_blk;
   if (p1 > n_pix) p1 = n_pix;
-  for (int64_t p = p0 + tid; p < p1; p += CD_THREADS) {
+  for (int64_t p = p0 + pr; pr < PR && p < p1; p += PR) {
     float g[CO], xv[V], d[V];
     vload<T, CO>(dy + p * CO, g);
     vload<T, V>(x + p * Cin + c0, xv);
@@ -243,28 +248,24 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
     }
     if (dx) vstore<T, V>(dx + p * Cin + c0, d);
   }
-  constexpr int NR = CO * V + CO;
 #pragma unroll
   for (int j = 0; j < CO; j++) {
 #pragma unroll
-    for (int k = 0; k < V; k++) {
-      const float s = wave_sum(aw[j][k]);
-      if (lane == 0) red[wid * NR + j * V + k] = s;
-    }
-    const float s = wave_sum(ab[j]);
-    if (lane == 0) red[wid * NR + CO * V + j] = s;
+    for (int k = 0; k < V; k++) red[tid * NR + j * V + k] = aw[j][k];
+    red[tid * NR + CO * V + j] = ab[j];
   }
   __syncthreads();
-  if (tid < NR) {
-    float s = 0.f;
-    for (int w2 = 0; w2 < CD_THREADS / 64; w2++) s += red[w2 * NR + tid];
-    float* prow = partials + (int64_t)blockIdx.x * (CO * Cin + CO);
-    if (tid < CO * V) {
-      const int j = tid / V, k = tid % V;
-      prow[j * Cin + c0 + k] = s;
-    } else if (blockIdx.y == 0) {
-      prow[CO * Cin + (tid - CO * V)] = s;
+  float* prow = partials + (int64_t)blockIdx.x * (CO * Cin + CO);
+  for (int o = tid; o < CO * Cin + CO; o += CD_THREADS) {
+    float acc = 0.f;
+    if (o < CO * Cin) {
+      const int j = o / Cin, c = o % Cin, ocv = c / V, k = c % V;
+      for (int r = 0; r < PR; r++) acc += red[(r * CV + ocv) * NR + j * V + k];
+    } else {
+      const int j = o - CO * Cin;
+      for (int r = 0; r < PR; r++) acc += red[(r * CV) * NR + CO * V + j];     // cv == 0 lanes
     }
+    prow[o] = acc;
   }
 }
 
@@ -277,7 +278,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   }
 }
 
-constexpr int C1_MAX_BLOCKS = 512;
+constexpr int C1_MAX_BLOCKS = 1024;
 
 template <typename T, int CO>
 int conv1x1_fwd_t(const void* x, int64_t n_pix, int Cin, const float* w, const float* bias, void* y, hipStream_t st) {
@@ -295,17 +296,23 @@ template <typename T, int CO>
 int conv1x1_bwd_t(const void* x, const void* dy, int64_t n_pix, int Cin, const float* w, void* dx, float* dw,
                   float* dbias, void* ws, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
-  int nblk = (int)((n_pix + CD_THREADS * 8 - 1) / (CD_THREADS * 8));
+  const bool vec = pick_vec<T>(Cin, x, dx) == N && (CD_THREADS % (Cin / N)) == 0;
+  const int V = vec ? N : 1;
+  const int PR = CD_THREADS / (Cin / V);
+  int nblk = (int)((n_pix + (int64_t)PR * 16 - 1) / ((int64_t)PR * 16));
   if (nblk > C1_MAX_BLOCKS) nblk = C1_MAX_BLOCKS;
   if (nblk < 1) nblk = 1;
   const int64_t ppb = (n_pix + nblk - 1) / nblk;
   float* partials = (float*)ws;
-  if (pick_vec<T>(Cin, x, dx) == N)
-    conv1x1_bwd_kernel<T, N, CO><<<dim3(nblk, Cin / N), CD_THREADS, 0, st>>>((const T*)x, (const T*)dy, w, (T*)dx,
-                                                                               partials, n_pix, Cin, ppb);
-  else
-    conv1x1_bwd_kernel<T, 1, CO><<<dim3(nblk, Cin), CD_THREADS, 0, st>>>((const T*)x, (const T*)dy, w, (T*)dx,
-                                                                          partials, n_pix, Cin, ppb);
+  const size_t lds = (size_t)CD_THREADS * (CO * V + CO) * sizeof(float);
+  if (vec) {
+    auto k = conv1x1_bwd_kernel<T, N, CO>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k<<<nblk, CD_THREADS, lds, st>>>((const T*)x, (const T*)dy, w, (T*)dx, partials, n_pix, Cin, ppb);
+  } else {
+    conv1x1_bwd_kernel<T, 1, CO><<<nblk, CD_THREADS, lds, st>>>((const T*)x, (const T*)dy, w, (T*)dx, partials, n_pix,
+                                                                 Cin, ppb);
+  }
   launch_reduce_partials(partials, nblk, CO * Cin, dw, st, CO * Cin + CO);
   launch_reduce_partials(partials + CO * Cin, nblk, CO, dbias, st, CO * Cin + CO);
   return 0;

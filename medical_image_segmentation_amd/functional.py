@@ -225,10 +225,12 @@ class ConvBnReluFn(torch.autograd.Function):
         # eval mode: statistics are constants, so the two projection terms vanish
         proj = sums if ctx.training else torch.zeros_like(sums)
         dz = torch.empty_like(z)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dbias = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
         with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
             call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
-                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(), st)
-        dbias = channel_sum_raw(dz) if ctx.has_bias and ctx.needs_input_grad[2] else None
+                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
+                 dbias.data_ptr() if want_db else None, ws.data_ptr(), st)
         dx = None
         if ctx.needs_input_grad[0]:
             wd = pack_weights(weight.detach(), x.dtype, transposed=True)
