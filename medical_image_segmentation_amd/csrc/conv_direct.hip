@@ -45,66 +45,85 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
   const int tid = threadIdx.x;
   const int co0 = blockIdx.y * CO_T;
   const int64_t n_pix = (int64_t)B * H * W;
-  const int64_t pix = (int64_t)blockIdx.x * CD_THREADS + tid;
-  const bool valid = pix < n_pix;
-  int px = 0, py = 0;
-  if (valid) {
-    px = (int)(pix % W);
-    py = (int)((pix / W) % H);
-  }
-  float acc[CO_T];
+  const bool one_chunk = Cin <= CI_CHUNK;           // weights staged once for the whole pixel walk
+  float st[2 * CO_T];
 #pragma unroll
-  for (int j = 0; j < CO_T; j++) acc[j] = 0.f;
+  for (int j = 0; j < 2 * CO_T; j++) st[j] = 0.f;
+  float bv[CO_T];
+#pragma unroll
+  for (int j = 0; j < CO_T; j++) bv[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
 
-  for (int c0 = 0; c0 < Cin; c0 += CI_CHUNK) {
-    const int cn = (Cin - c0 < CI_CHUNK) ? (Cin - c0) : CI_CHUNK;
-    __syncthreads();
+  auto stage_w = [&](int c0, int cn) {
     for (int i = tid; i < 9 * CI_CHUNK * CO_T; i += CD_THREADS) {
       const int j = i % CO_T, ci = (i / CO_T) % CI_CHUNK, tap = i / (CO_T * CI_CHUNK);
       float v = 0.f;
       if (ci < cn && co0 + j < Cout) v = to_f32(wp[((int64_t)tap * Cout + co0 + j) * Cin + c0 + ci]);
       wl[tap][ci][j] = v;
     }
+  };
+  if (one_chunk) {
+    stage_w(0, Cin);
     __syncthreads();
+  }
+  // persistent walk over 256-pixel groups (trip count is block-uniform: barriers inside are safe)
+  for (int64_t pix0 = (int64_t)blockIdx.x * CD_THREADS; pix0 < n_pix; pix0 += (int64_t)gridDim.x * CD_THREADS) {
+    const int64_t pix = pix0 + tid;
+    const bool valid = pix < n_pix;
+    int px = 0, py = 0;
     if (valid) {
+      px = (int)(pix % W);
+      py = (int)((pix / W) % H);
+    }
+    float acc[CO_T];
 #pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        const T* xp = x + (pix + (int64_t)(tap / 3 - 1) * W + (tap % 3 - 1)) * Cin + c0;
-        for (int ci = 0; ci < cn; ci += V) {
-          float xv[V];
-          vload<T, V>(xp + ci, xv);
+    for (int j = 0; j < CO_T; j++) acc[j] = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += CI_CHUNK) {
+      const int cn = (Cin - c0 < CI_CHUNK) ? (Cin - c0) : CI_CHUNK;
+      if (!one_chunk) {
+        __syncthreads();
+        stage_w(c0, cn);
+        __syncthreads();
+      }
+      if (valid) {
 #pragma unroll
-          for (int k = 0; k < V; k++)
+        for (int tap = 0; tap < 9; tap++) {
+          const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+          const T* xp = x + (pix + (int64_t)(tap / 3 - 1) * W + (tap % 3 - 1)) * Cin + c0;
+          for (int ci = 0; ci < cn; ci += V) {
+            float xv[V];
+            vload<T, V>(xp + ci, xv);
 #pragma unroll
-            for (int j = 0; j < CO_T; j++) acc[j] += xv[k] * wl[tap][ci + k][j];
+            for (int k = 0; k < V; k++)
+#pragma unroll
+              for (int j = 0; j < CO_T; j++) acc[j] += xv[k] * wl[tap][ci + k][j];
+          }
         }
       }
     }
-  }
-  float st[2 * CO_T];
 #pragma unroll
-  for (int j = 0; j < CO_T; j++) {
-    const float b = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
-    acc[j] += b;
-    st[j] = valid ? acc[j] : 0.f;
-    st[CO_T + j] = valid ? acc[j] * acc[j] : 0.f;
-  }
-  if (valid) {
-    T* zp = z + pix * Cout + co0;
-    if (co0 + CO_T <= Cout && (Cout % CO_T) == 0 && sizeof(T) * CO_T >= 16) {
-      if constexpr (sizeof(T) == 2) {
-        vstore<T, CO_T>(zp, acc);
-      } else {
-        float lo[4] = {acc[0], acc[1], acc[2], acc[3]}, hi[4] = {acc[4], acc[5], acc[6], acc[7]};
-        vstore<T, 4>(zp, lo);
-        vstore<T, 4>(zp + 4, hi);
+    for (int j = 0; j < CO_T; j++) {
+      acc[j] += bv[j];
+      if (valid) {
+        st[j] += acc[j];
+        st[CO_T + j] += acc[j] * acc[j];
       }
-    } else {
+    }
+    if (valid) {
+      T* zp = z + pix * Cout + co0;
+      if (co0 + CO_T <= Cout && (Cout % CO_T) == 0 && sizeof(T) * CO_T >= 16) {
+        if constexpr (sizeof(T) == 2) {
+          vstore<T, CO_T>(zp, acc);
+        } else {
+          float lo[4] = {acc[0], acc[1], acc[2], acc[3]}, hi[4] = {acc[4], acc[5], acc[6], acc[7]};
+          vstore<T, 4>(zp, lo);
+          vstore<T, 4>(zp + 4, hi);
+        }
+      } else {
 #pragma unroll
-      for (int j = 0; j < CO_T; j++)
-        if (co0 + j < Cout) zp[j] = from_f32<T>(acc[j]);
+        for (int j = 0; j < CO_T; j++)
+          if (co0 + j < Cout) zp[j] = from_f32<T>(acc[j]);
+      }
     }
   }
   if (partials) {
@@ -343,14 +362,18 @@ int conv1x1_bwd_t(const void* x, const void* dy, int64_t n_pix, int Cin, const f
 // Entry points shared with the MFMA file (declared in conv_internal.h).
 #include "conv_internal.h"
 
+constexpr int CD_MAX_BLOCKS = 1024;
+
 size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout) {
-  return align256((size_t)cdiv(n_pix, CD_THREADS) * 2 * Cout * sizeof(float));
+  return align256((size_t)CD_MAX_BLOCKS * 2 * Cout * sizeof(float));
 }
 
 int conv3x3_direct_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
                        int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
   const int64_t n_pix = (int64_t)B * H * W;
-  dim3 grid(cdiv(n_pix, CD_THREADS), cdiv(Cout, CO_T));
+  int gx = cdiv(n_pix, CD_THREADS);
+  if (gx > CD_MAX_BLOCKS) gx = CD_MAX_BLOCKS;
+  dim3 grid(gx, cdiv(Cout, CO_T));
   float* partials = stats ? (float*)workspace : nullptr;
   if (dtype == MIS_F32) {
     if (Cin % 4 == 0 && ((uintptr_t)x % 16) == 0)

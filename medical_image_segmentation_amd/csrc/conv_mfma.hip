@@ -26,14 +26,16 @@
 // algorithmic flops = 2*9*B*H*W*Cin*Cout.
 #include "conv_internal.h"
 #include "reduce.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int TH = 16, TW = 16;          // output tile
+constexpr int TW = 16;                   // output tile width; tile height = 4 waves x MT rows
 constexpr int HW_ = TW + 2;              // halo width
-constexpr int HP = (TH + 2) * HW_;       // halo positions (324)
 constexpr int CM_THREADS = 256;
-constexpr int MT = 4;                    // tile rows (16-pixel MFMA columns) per wave
+// rows per wave: taller tiles where the register budget allows (narrow Cout, short K chunks)
+constexpr int fwd_mt(int nt, int cpg) { return 4; }   // (8-row variants measured slower: occupancy loss)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 template <typename T> struct Mf;
 template <> struct Mf<bf16> {
@@ -101,6 +103,9 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
   using Frag = typename Mf<T>::Frag;
   constexpr int NS = nsteps_of(CPG);
   constexpr int KC = CPG * G;
+  constexpr int MT = fwd_mt(NT, CPG);      // tile rows per wave
+  constexpr int TH = 4 * MT;               // tile height
+  constexpr int HP = (TH + 2) * HW_;       // halo positions
   constexpr int HALO_VECS = HP * CPG;
   constexpr int HALO_IT = (HALO_VECS + CM_THREADS - 1) / CM_THREADS;
   constexpr int W_VECS = NS * NT * 64;
@@ -114,7 +119,6 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
   const int n0 = blockIdx.y * NT;                 // first n-tile of this workgroup
-  const uint4* wsrc = reinterpret_cast<const uint4*>(wp);
 
   // per-lane tap offsets of each MFMA step (positions inside the halo) and channel group
   // (with 4 groups per position a step is exactly one tap: offsets are compile-time constants)
@@ -137,52 +141,61 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 4; r++) s1[n][r] = s2[n][r] = 0.f;
 
-  uint4 hreg[HALO_IT], wreg[W_IT];
+  u32x4 hreg[HALO_IT], wreg[W_IT];
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, n_chunks * NS * nt_total * 1024, 0x00020000);
 
-#define LOAD_HALO(TILE, CHUNK)                                                                           \
+  // Global loads go through buffer descriptors: an out-of-range offset returns zeros in
+  // hardware, which implements the conv's zero padding (and the tail guards) without a branch
+  // or a select on the loaded value — so the loads stay in flight under the MFMAs.
+  constexpr int OOB = 0x7FFFFFFF;
+  const int img_bytes = H * W * Cin * (int)sizeof(T);
+#define LOAD_HALO(TILE, CHUNK, LIVE)                                                                     \
   {                                                                                                      \
-    const int t_ = (TILE);                                                                               \
+    const bool live_ = (LIVE);                                                                           \
+    const int t_ = live_ ? (TILE) : 0;                                                                   \
     const int tx_ = t_ % tiles_x, ty_ = (t_ / tiles_x) % tiles_y, b_ = t_ / (tiles_x * tiles_y);         \
     const int y0_ = ty_ * TH - 1, x0_ = tx_ * TW - 1;                                                    \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                \
+        (void*)(x + (int64_t)b_ * H * W * Cin), 0, img_bytes, 0x00020000);                               \
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
       const int v = tid + i * CM_THREADS;                                                                \
       const int pos = v / CPG, cg = v % CPG;                                                             \
       const int gy = y0_ + pos / HW_, gx = x0_ + pos % HW_;                                              \
-      const bool ok = (v < HALO_VECS) && gy >= 0 && gy < H && gx >= 0 && gx < W;                         \
-      const T* src = x + (((int64_t)b_ * H + gy) * W + gx) * Cin + (CHUNK) * KC + cg * G;                \
-      hreg[i] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);                      \
+      const bool ok = live_ && (v < HALO_VECS) && gy >= 0 && gy < H && gx >= 0 && gx < W;                \
+      const int off = ((gy * W + gx) * Cin + (CHUNK) * KC + cg * G) * (int)sizeof(T);                    \
+      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : OOB, 0, 0);                        \
     }                                                                                                    \
   }
 #define STORE_HALO()                                                                                     \
   {                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
       const int v = tid + i * CM_THREADS;                                                                \
-      if (v < HALO_VECS) halo[halo_slot<CPG>(v / CPG, v % CPG)] = hreg[i];                               \
+      if (v < HALO_VECS) *reinterpret_cast<u32x4*>(&halo[halo_slot<CPG>(v / CPG, v % CPG)]) = hreg[i];   \
     }                                                                                                    \
   }
-#define LOAD_W(CHUNK)                                                                                    \
+#define LOAD_W(CHUNK, LIVE)                                                                              \
   {                                                                                                      \
+    const bool live_ = (LIVE);                                                                           \
     _Pragma("unroll") for (int i = 0; i < W_IT; i++) {                                                   \
       const int v = tid + i * CM_THREADS;                                                                \
       const int s_ = v / (NT * 64), rem = v % (NT * 64);                                                 \
-      wreg[i] = (v < W_VECS) ? wsrc[((int64_t)((CHUNK) * NS + s_) * nt_total + n0) * 64 + rem]             \
-                             : make_uint4(0, 0, 0, 0);                                                     \
+      const int off = ((((CHUNK) * NS + s_) * nt_total + n0) * 64 + rem) * 16;                           \
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (live_ && v < W_VECS) ? off : OOB, 0, 0);     \
     }                                                                                                    \
   }
 #define STORE_W()                                                                                        \
   {                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < W_IT; i++) {                                                   \
       const int v = tid + i * CM_THREADS;                                                                \
-      if (v < W_VECS) wl[v] = wreg[i];                                                                   \
+      if (v < W_VECS) *reinterpret_cast<u32x4*>(&wl[v]) = wreg[i];                                       \
     }                                                                                                    \
   }
 
   const bool w_resident = (n_chunks == 1);
   int tile = blockIdx.x;
-  if (tile < n_tiles) {
-    LOAD_HALO(tile, 0)
-    LOAD_W(0)
-  }
+  LOAD_HALO(tile, 0, tile < n_tiles)
+  LOAD_W(0, tile < n_tiles)
   bool first = true;
   for (; tile < n_tiles; tile += gridDim.x) {
     f32x4 acc[MT][NT];
@@ -204,10 +217,10 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
           nchunk = 0;
           ntile = tile + gridDim.x;
         }
-        if (ntile < n_tiles) {
-          LOAD_HALO(ntile, nchunk)
-          if (!w_resident) LOAD_W(nchunk)
-        }
+        // unconditional issue (dead stages read out of range = zeros): no control flow between
+        // the loads and the MFMAs, so nothing forces an early wait on them
+        LOAD_HALO(ntile, nchunk, ntile < n_tiles)
+        LOAD_W(nchunk, !w_resident && ntile < n_tiles)
       }
 #pragma unroll
       for (int s = 0; s < NS; s++) {
@@ -250,18 +263,67 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
       const int gy = ty * TH + wid * MT + m;
       const bool pv = (gy < H) && (gx < W);
       T* zp = z + (((int64_t)b * H + gy) * W + gx) * Cout;
+      if constexpr (sizeof(T) == 2 && NT >= 2) {
+        // bf16, >= 32 channels: lanes (kg, kg^1) of a pixel swap halves of a tile pair so every lane
+        // stores 16 bytes = 8 consecutive channels, and the 4 lanes of a pixel one contiguous 64 bytes
 #pragma unroll
-      for (int n = 0; n < NT; n++) {
-        const int co = (n0 + n) * 16 + 4 * kg;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = acc[m][n][r] + bv[n][r];
-        if (pv && co < Cout) {
-          vstore<T, 4>(zp + co, v);
+        for (int n = 0; n < NT; n += 2) {
+          float va[4], vb[4];
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            s1[n][r] += v[r];
-            s2[n][r] += v[r] * v[r];
+            va[r] = acc[m][n][r] + bv[n][r];
+            vb[r] = acc[m][n + 1][r] + bv[n + 1][r];
+          }
+          const int coa = (n0 + n) * 16 + 4 * kg, cob = coa + 16;
+          if (pv && coa < Cout) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              s1[n][r] += va[r];
+              s2[n][r] += va[r] * va[r];
+            }
+          }
+          if (pv && cob < Cout) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              s1[n + 1][r] += vb[r];
+              s2[n + 1][r] += vb[r] * vb[r];
+            }
+          }
+          union { bf16 h[4]; unsigned int u[2]; } pa, pb;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            pa.h[r] = from_f32<bf16>(va[r]);
+            pb.h[r] = from_f32<bf16>(vb[r]);
+          }
+          const bool odd = kg & 1;
+          // even kg keeps tile n and receives the partner's tile n; odd kg keeps tile n+1
+          const unsigned int s0 = odd ? pa.u[0] : pb.u[0], s1x = odd ? pa.u[1] : pb.u[1];
+          const unsigned int r0 = __shfl_xor(s0, 16, WAVE), r1 = __shfl_xor(s1x, 16, WAVE);
+          u32x4 out;
+          if (!odd) out = u32x4{pa.u[0], pa.u[1], r0, r1};      // channels 4kg .. 4kg+7 of tile n
+          else out = u32x4{r0, r1, pb.u[0], pb.u[1]};           // channels 4(kg-1) .. 4(kg-1)+7 of tile n+1
+          const int co = odd ? (cob - 4) : coa;
+          if (pv && co + 7 < Cout && (Cout & 7) == 0) *reinterpret_cast<u32x4*>(zp + co) = out;
+          else if (pv) {
+            // ragged channel tail (Cout not a multiple of 8 inside this pair): 4-channel stores
+            if (coa < Cout) vstore<T, 4>(zp + coa, va);
+            if (cob < Cout) vstore<T, 4>(zp + cob, vb);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+          const int co = (n0 + n) * 16 + 4 * kg;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] = acc[m][n][r] + bv[n][r];
+          if (pv && co < Cout) {
+            vstore<T, 4>(zp + co, v);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              s1[n][r] += v[r];
+              s2[n][r] += v[r] * v[r];
+            }
           }
         }
       }
@@ -323,14 +385,21 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
   p.NT = p.nt_total >= 4 ? 4 : (p.nt_total >= 2 ? 2 : 1);
   if (p.nt_total % p.NT != 0) p.NT = (p.nt_total % 2 == 0) ? 2 : 1;
   p.grid_y = p.nt_total / p.NT;
+  const int TH = 4 * fwd_mt(p.NT, p.CPG);
   p.tiles_x = (W + TW - 1) / TW;
   p.tiles_y = (H + TH - 1) / TH;
   p.n_tiles = B * p.tiles_x * p.tiles_y;
-  int gx = 768 / p.grid_y;                    // ~3 workgroups per CU over the whole launch
+  static int target = -1;                     // total workgroups per launch (MIS_CONV_GRID overrides, tuning)
+  if (target < 0) {
+    const char* e = getenv("MIS_CONV_GRID");
+    target = e ? atoi(e) : 768;
+    if (target < 64) target = 768;
+  }
+  int gx = target / p.grid_y;
   if (gx < 256) gx = 256;
   if (gx > p.n_tiles) gx = p.n_tiles;
   p.grid_x = gx;
-  p.lds = (size_t)HP * p.CPG * 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024;
+  p.lds = (size_t)(TH + 2) * HW_ * p.CPG * 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024;
   return true;
 }
 
@@ -386,7 +455,7 @@ bool conv3x3_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout) {
 }
 
 size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout) {
-  return align256((size_t)1024 * 2 * Cout * sizeof(float));
+  return align256((size_t)8192 * 2 * Cout * sizeof(float));
 }
 
 size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout) {
@@ -473,11 +542,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int lane_of
 }
 
 template <typename T, int MTO, int NTI, int WCO, int WCI, int WK>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dz,
+__global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dz,
                                                                  float* __restrict__ slab, int B, int H, int W,
                                                                  int Cin, int Cout, int n_ci_blocks, int tiles_x,
                                                                  int tiles_y, int n_tiles) {
-  static_assert(WCO * WCI * WK == 4, "4 waves");
+  constexpr int NTHR = 64 * WCO * WCI * WK;
   constexpr int G = Mf<T>::G;
   constexpr int TH = WgT<T>::TH;
   constexpr int HWW = WG_TW + 2;                 // halo width 34
@@ -486,7 +555,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
   constexpr int CTO = WCO * MTO * 16, CTI = WCI * NTI * 16;
   constexpr int XVP = CTI / G, ZVP = CTO / G;    // 16-byte vectors per position
   constexpr int XV = PH * XVP, ZV = PZ * ZVP;
-  constexpr int XIT = (XV + 255) / 256, ZIT = (ZV + 255) / 256;
+  constexpr int XIT = (XV + NTHR - 1) / NTHR, ZIT = (ZV + NTHR - 1) / NTHR;
   constexpr int RSX = padded_row_bytes(CTI * (int)sizeof(T)), RSZ = padded_row_bytes(CTO * (int)sizeof(T));
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -506,42 +575,50 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
 #pragma unroll
       for (int ni = 0; ni < NTI; ni++) acc[t][mo][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 xr[XIT], zr[ZIT];
-#define WG_LOAD(TILE)                                                                                   \
+  u32x4 xr[XIT], zr[ZIT];
+  constexpr int OOB = 0x7FFFFFFF;
+  const int ximg_bytes = H * W * Cin * (int)sizeof(T), zimg_bytes = H * W * Cout * (int)sizeof(T);
+  // buffer loads: out-of-range offsets (padding, tile tails, channel tails, dead stages) read zeros
+#define WG_LOAD(TILE, LIVE)                                                                             \
   {                                                                                                     \
-    const int t_ = (TILE);                                                                              \
+    const bool live_ = (LIVE);                                                                          \
+    const int t_ = live_ ? (TILE) : 0;                                                                  \
     const int tx_ = t_ % tiles_x, ty_ = (t_ / tiles_x) % tiles_y, b_ = t_ / (tiles_x * tiles_y);        \
     const int y0_ = ty_ * TH, x0_ = tx_ * WG_TW;                                                        \
+    const __amdgpu_buffer_rsrc_t xrs_ = __builtin_amdgcn_make_buffer_rsrc(                              \
+        (void*)(x + (int64_t)b_ * H * W * Cin), 0, ximg_bytes, 0x00020000);                             \
+    const __amdgpu_buffer_rsrc_t zrs_ = __builtin_amdgcn_make_buffer_rsrc(                              \
+        (void*)(dz + (int64_t)b_ * H * W * Cout), 0, zimg_bytes, 0x00020000);                           \
     _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                   \
-      const int v = tid + i * 256;                                                                      \
+      const int v = tid + i * NTHR;                                                                      \
       const int pos = v / XVP, cv = v % XVP;                                                            \
       const int gy = y0_ - 1 + pos / HWW, gx = x0_ - 1 + pos % HWW;                                     \
       const int c = ci0 + cv * G;                                                                       \
-      const bool ok = (v < XV) && gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cin;                    \
-      xr[i] = ok ? *reinterpret_cast<const uint4*>(x + (((int64_t)b_ * H + gy) * W + gx) * Cin + c)     \
-                 : make_uint4(0, 0, 0, 0);                                                              \
+      const bool ok = live_ && (v < XV) && gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cin;           \
+      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(                                                    \
+          xrs_, ok ? ((gy * W + gx) * Cin + c) * (int)sizeof(T) : OOB, 0, 0);                           \
     }                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < ZIT; i++) {                                                   \
-      const int v = tid + i * 256;                                                                      \
+      const int v = tid + i * NTHR;                                                                      \
       const int pos = v / ZVP, cv = v % ZVP;                                                            \
       const int gy = y0_ + pos / WG_TW, gx = x0_ + pos % WG_TW;                                         \
       const int c = co0 + cv * G;                                                                       \
-      const bool ok = (v < ZV) && gy < H && gx < W && c < Cout;                                         \
-      zr[i] = ok ? *reinterpret_cast<const uint4*>(dz + (((int64_t)b_ * H + gy) * W + gx) * Cout + c)   \
-                 : make_uint4(0, 0, 0, 0);                                                              \
+      const bool ok = live_ && (v < ZV) && gy < H && gx < W && c < Cout;                                \
+      zr[i] = __builtin_amdgcn_raw_buffer_load_b128(                                                    \
+          zrs_, ok ? ((gy * W + gx) * Cout + c) * (int)sizeof(T) : OOB, 0, 0);                          \
     }                                                                                                   \
   }
 #define WG_STORE()                                                                                      \
   {                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                   \
-      const int v = tid + i * 256;                                                                      \
+      const int v = tid + i * NTHR;                                                                      \
       const int pos = v / XVP, cv = v % XVP;                                                            \
-      if (v < XV) *reinterpret_cast<uint4*>(xh + pos * RSX + cv * 16) = xr[i];                          \
+      if (v < XV) *reinterpret_cast<u32x4*>(xh + pos * RSX + cv * 16) = xr[i];                          \
     }                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < ZIT; i++) {                                                   \
-      const int v = tid + i * 256;                                                                      \
+      const int v = tid + i * NTHR;                                                                      \
       const int pos = v / ZVP, cv = v % ZVP;                                                            \
-      if (v < ZV) *reinterpret_cast<uint4*>(zt + pos * RSZ + cv * 16) = zr[i];                          \
+      if (v < ZV) *reinterpret_cast<u32x4*>(zt + pos * RSZ + cv * 16) = zr[i];                          \
     }                                                                                                   \
   }
 
@@ -551,12 +628,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
   const int offz = k_pixel(lg, 0, lq) * RSZ + 8 * lp + wco * MTO * 32;
 
   int tile = blockIdx.x;
-  if (tile < n_tiles) WG_LOAD(tile)
+  WG_LOAD(tile, tile < n_tiles)
   for (; tile < n_tiles; tile += gridDim.x) {
     __syncthreads();
     WG_STORE()
     __syncthreads();
-    if (tile + (int)gridDim.x < n_tiles) WG_LOAD(tile + gridDim.x)
+    WG_LOAD(tile + (int)gridDim.x, tile + (int)gridDim.x < n_tiles)
 
     for (int r = wk; r < TH; r += WK) {
       if constexpr (sizeof(T) == 2) {
@@ -603,7 +680,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
 
   // sum the WK row-split waves through LDS (wave wk=0 of each (wco,wci) keeps the total)
   if constexpr (WK > 1) {
-    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + (wco * WCI + wci) * (9 * MTO * NTI * 64);
     for (int src = 1; src < WK; src++) {
       __syncthreads();
       if (wk == src) {
@@ -642,31 +719,38 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const T* __rest
   }
 }
 
-// dw[co][ci][tap] = sum_s slab[s][tap][ci][co]; 32 row lanes x 32 columns per workgroup, fixed order.
+// dw[co][ci][tap] = sum_s slab[s][tap][ci][co].  RL row lanes x (1024/RL) columns per workgroup:
+// many lanes per column when there are many splits and few outputs, one lane per column
+// (pure streaming) when the weight tensor is large and the splits few.  Fixed order.
+template <int RL>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cin,
                                                             int Cout, float* __restrict__ dw) {
-  __shared__ double red[32][33];
+  constexpr int COLS = 1024 / RL;
+  __shared__ double red[RL > 1 ? RL : 1][RL > 1 ? COLS + 1 : 1];
   const int n = 9 * Cin * Cout;
-  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + c;
+  const int c = threadIdx.x % COLS, r = threadIdx.x / COLS;
+  const int j = blockIdx.x * COLS + c;
   double s = 0.0;
   if (j < n) {
     int i = r;
-    for (; i + 96 < nsplit; i += 128) {
-      const float a0 = slab[(int64_t)i * n + j], a1 = slab[(int64_t)(i + 32) * n + j];
-      const float a2 = slab[(int64_t)(i + 64) * n + j], a3 = slab[(int64_t)(i + 96) * n + j];
+    for (; i + 3 * RL < nsplit; i += 4 * RL) {
+      const float a0 = slab[(int64_t)i * n + j], a1 = slab[(int64_t)(i + RL) * n + j];
+      const float a2 = slab[(int64_t)(i + 2 * RL) * n + j], a3 = slab[(int64_t)(i + 3 * RL) * n + j];
       s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
     }
-    for (; i < nsplit; i += 32) s += (double)slab[(int64_t)i * n + j];
+    for (; i < nsplit; i += RL) s += (double)slab[(int64_t)i * n + j];
   }
-  red[r][c] = s;
-  __syncthreads();
-  if (r == 0 && j < n) {
-    double t = 0.0;
+  if constexpr (RL > 1) {
+    red[r][c] = s;
+    __syncthreads();
+    if (r != 0) return;
+    s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 32; k++) t += red[k][c];
+    for (int k = 0; k < RL; k++) s += red[k][c];
+  }
+  if (j < n) {
     const int co = j % Cout, ci = (j / Cout) % Cin, tap = j / (Cout * Cin);
-    dw[((int64_t)co * Cin + ci) * 9 + tap] = (float)t;
+    dw[((int64_t)co * Cin + ci) * 9 + tap] = (float)s;
   }
 }
 
@@ -691,15 +775,24 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p) {
   p.tiles_x = (W + WG_TW - 1) / WG_TW;
   p.tiles_y = (H + TH - 1) / TH;
   p.n_tiles = B * p.tiles_x * p.tiles_y;
+  // K-splits: enough workgroups to fill the chip, but the slab traffic (nsplit * dW bytes, written
+  // and read once) must stay below the activation traffic of the layer
   const int nout = p.n_co_blocks * p.n_ci_blocks;
-  int ns = 1024 / nout;
-  if (ns < 1) ns = 1;
+  const double act_bytes = (double)B * H * W * (Cin + Cout) * sizeof(T);
+  const double dw_bytes = 36.0 * Cin * Cout;
+  int ns = 768 / nout;
+  const int ns_slab = (int)(act_bytes / dw_bytes);
+  if (ns > ns_slab) ns = ns_slab;
+  const int ns_fill = (256 + nout - 1) / nout;          // at least one workgroup per CU
+  if (ns < ns_fill) ns = ns_fill;
   if (ns > p.n_tiles) ns = p.n_tiles;
   if (ns > 1024) ns = 1024;
+  if (ns < 1) ns = 1;
   p.nsplit = ns;
   const size_t tiles = (size_t)(TH + 2) * (WG_TW + 2) * padded_row_bytes(p.CTI * (int)sizeof(T)) +
                        (size_t)TH * WG_TW * padded_row_bytes(p.CTO * (int)sizeof(T));
-  const size_t redb = (p.cfg == 4) ? 0 : (size_t)9 * (p.CTO / 16) * (p.CTI / 16) * 64 * 16;
+  // K-split reduction scratch: one 9 x (tiles per wave) x 1 KiB region per (co,ci) wave group
+  const size_t redb = (size_t)9 * (p.CTO / 16) * (p.CTI / 16) * 64 * 16;
   p.lds = tiles > redb ? tiles : redb;
   return true;
 }
@@ -719,19 +812,25 @@ int run_wgrad(const void* x, const void* dz, int B, int H, int W, int Cin, int C
     auto kfn = conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK>;                                       \
     if (p.lds > 48 * 1024)                                                                                 \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
-    kfn<<<grid, 256, p.lds, st>>>((const T*)x, (const T*)dz, slab, B, H, W, Cin, Cout, p.n_ci_blocks,      \
-                                  p.tiles_x, p.tiles_y, p.n_tiles);                                        \
+    kfn<<<grid, 64 * WCO * WCI * WK, p.lds, st>>>((const T*)x, (const T*)dz, slab, B, H, W, Cin, Cout,     \
+                                                  p.n_ci_blocks, p.tiles_x, p.tiles_y, p.n_tiles);         \
   }
   switch (p.cfg) {
     case 0: WG_LAUNCH(1, 1, 1, 1, 4); break;
     case 1: WG_LAUNCH(2, 1, 1, 1, 4); break;
     case 2: WG_LAUNCH(1, 2, 1, 1, 4); break;
-    case 3: WG_LAUNCH(2, 2, 1, 1, 4); break;
-    default: WG_LAUNCH(2, 2, 2, 2, 1); break;
+    case 3: WG_LAUNCH(2, 1, 1, 2, 2); break;
+    default: WG_LAUNCH(2, 2, 2, 2, 2); break;
   }
 #undef WG_LAUNCH
   MIS_CHECK_LAUNCH("conv3x3_wgrad_mfma_kernel");
-  wgrad_reduce_kernel<<<cdiv(9 * Cin * Cout, 32), 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
+  const int nout = 9 * Cin * Cout;
+  if (p.nsplit <= 16 || nout >= (1 << 18))
+    wgrad_reduce_kernel<1><<<cdiv(nout, 1024), 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
+  else if (p.nsplit <= 128)
+    wgrad_reduce_kernel<4><<<cdiv(nout, 256), 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
+  else
+    wgrad_reduce_kernel<32><<<cdiv(nout, 32), 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
   MIS_CHECK_LAUNCH("wgrad_reduce_kernel");
   return MIS_OK;
 }
