@@ -42,6 +42,16 @@ namespace {
 
 constexpr int EW_THREADS = 256;
 
+// Largest grid <= min(want, cap) such that grid*256 is a multiple of CV (so that a grid-stride
+// thread keeps one channel vector); at least the smallest such grid.
+inline int grid_for_fixed_channels(int want, int CV, int cap) {
+  int g = 1;
+  while (((int64_t)g * EW_THREADS) % CV != 0) g++;
+  if (want > cap) want = cap;
+  int grid = (want / g) * g;
+  return grid < g ? g : grid;
+}
+
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double inv_n, double unbias,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -75,20 +85,26 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ rm, const float*
   scale_shift[C + c] = beta[c] - rm[c] * sc;
 }
 
+// The launcher sizes the grid so that grid*256 is a multiple of C/V: a thread then always works
+// on the same channel vector and keeps its scale/shift in registers.
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void bn_relu_apply_kernel(const T* __restrict__ z, T* __restrict__ a,
                                                                    int64_t n_vec, int C,
                                                                    const float* __restrict__ scale_shift) {
-  extern __shared__ float ss[];   // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) ss[i] = scale_shift[i];
-  __syncthreads();
   const int CV = C / V;
-  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS) {
-    const int c0 = (int)(i % CV) * V;
+  const int64_t i0 = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  const int c0 = (int)(i0 % CV) * V;
+  float sc[V], sh[V];
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    sc[k] = scale_shift[c0 + k];
+    sh[k] = scale_shift[C + c0 + k];
+  }
+  for (int64_t i = i0; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS) {
     float v[V];
     vload<T, V>(z + i * V, v);
 #pragma unroll
-    for (int k = 0; k < V; k++) v[k] = fmaxf(v[k] * ss[c0 + k] + ss[C + c0 + k], 0.f);
+    for (int k = 0; k < V; k++) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
     vstore<T, V>(a + i * V, v);
   }
 }
@@ -102,14 +118,24 @@ struct BnBwdReduce {
   const float* gamma;
   const float* beta;
   int C;
+  float mean[V], rstd[V], gam[V], bet[V];      // this thread's channel constants
+  __device__ __forceinline__ void prepare(int c0) {
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      mean[k] = mean_rstd[c0 + k];
+      rstd[k] = mean_rstd[C + c0 + k];
+      gam[k] = gamma[c0 + k];
+      bet[k] = beta[c0 + k];
+    }
+  }
   __device__ __forceinline__ void load(int64_t pix, int c0, float (&acc)[2][V]) const {
     float zv[V], gv[V];
     vload<T, V>(z + pix * C + c0, zv);
     vload<T, V>(da + pix * C + c0, gv);
 #pragma unroll
     for (int k = 0; k < V; k++) {
-      const float xh = (zv[k] - mean_rstd[c0 + k]) * mean_rstd[C + c0 + k];
-      const float y = xh * gamma[c0 + k] + beta[c0 + k];
+      const float xh = (zv[k] - mean[k]) * rstd[k];
+      const float y = xh * gam[k] + bet[k];
       const float dy = (y > 0.f) ? gv[k] : 0.f;
       acc[0][k] += dy;
       acc[1][k] += dy * xh;
@@ -122,6 +148,7 @@ struct ChannelSum {
   static constexpr int NOUT = 1;
   const T* x;
   int C;
+  __device__ __forceinline__ void prepare(int) {}
   __device__ __forceinline__ void load(int64_t pix, int c0, float (&acc)[1][V]) const {
     float v[V];
     vload<T, V>(x + pix * C + c0, v);
@@ -142,40 +169,40 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
                                                                     const float* __restrict__ beta,
                                                                     const float* __restrict__ sums,
                                                                     float* __restrict__ dz_partials) {
-  extern __shared__ float prm[];   // [7][C]: mean, rstd, gamma, beta, sum_dy/n, sum_dy_xhat/n, spare; then [256][V]
-  for (int i = threadIdx.x; i < C; i += EW_THREADS) {
-    prm[i] = mean_rstd[i];
-    prm[C + i] = mean_rstd[C + i];
-    prm[2 * C + i] = gamma[i];
-    prm[3 * C + i] = beta[i];
-    prm[4 * C + i] = sums[i] * inv_n;
-    prm[5 * C + i] = sums[C + i] * inv_n;
-    prm[6 * C + i] = 0.f;
-  }
-  __syncthreads();
+  extern __shared__ float prm[];   // scratch for the optional bias partial: [256][V]
   const int CV = C / V;
+  const int64_t i0 = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  const int c0 = (int)(i0 % CV) * V;
+  float mean[V], rstd[V], gam[V], bet[V], m1[V], m2[V];     // this thread's channel constants
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    mean[k] = mean_rstd[c0 + k];
+    rstd[k] = mean_rstd[C + c0 + k];
+    gam[k] = gamma[c0 + k];
+    bet[k] = beta[c0 + k];
+    m1[k] = sums[c0 + k] * inv_n;
+    m2[k] = sums[C + c0 + k] * inv_n;
+  }
   float bsum[V];
 #pragma unroll
   for (int k = 0; k < V; k++) bsum[k] = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS) {
-    const int c0 = (int)(i % CV) * V;
+  for (int64_t i = i0; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS) {
     float zv[V], gv[V], o[V];
     vload<T, V>(z + i * V, zv);
     vload<T, V>(da + i * V, gv);
 #pragma unroll
     for (int k = 0; k < V; k++) {
-      const int c = c0 + k;
-      const float xh = (zv[k] - prm[c]) * prm[C + c];
-      const float y = xh * prm[2 * C + c] + prm[3 * C + c];
+      const float xh = (zv[k] - mean[k]) * rstd[k];
+      const float y = xh * gam[k] + bet[k];
       const float dy = (y > 0.f) ? gv[k] : 0.f;
-      o[k] = prm[2 * C + c] * prm[C + c] * (dy - prm[4 * C + c] - xh * prm[5 * C + c]);
+      o[k] = gam[k] * rstd[k] * (dy - m1[k] - xh * m2[k]);
       bsum[k] += to_f32(from_f32<T>(o[k]));
     }
     vstore<T, V>(dz + i * V, o);
   }
   if (dz_partials) {
     // fixed-order block reduction: thread t holds channel vector (blockIdx*256 + t) % CV
-    float* red = prm + 7 * C;                  // [256][V]
+    float* red = prm;                          // [256][V]
 #pragma unroll
     for (int k = 0; k < V; k++) red[threadIdx.x * V + k] = bsum[k];
     __syncthreads();
@@ -193,11 +220,13 @@ template <typename T>
 int apply_t(const void* z, void* a, int64_t n_pix, int C, const float* ss, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = n_pix * C;
-  const size_t lds = 2 * (size_t)C * sizeof(float);
-  if (pick_vec<T>(C, z, a) == N)
-    bn_relu_apply_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>((const T*)z, (T*)a, n / N, C, ss);
+  const bool vec = pick_vec<T>(C, z, a) == N;
+  const int V = vec ? N : 1;
+  const int grid = grid_for_fixed_channels(ew_grid(n / V, EW_THREADS), C / V, 4096);
+  if (vec)
+    bn_relu_apply_kernel<T, N><<<grid, EW_THREADS, 0, st>>>((const T*)z, (T*)a, n / N, C, ss);
   else
-    bn_relu_apply_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>((const T*)z, (T*)a, n, C, ss);
+    bn_relu_apply_kernel<T, 1><<<grid, EW_THREADS, 0, st>>>((const T*)z, (T*)a, n, C, ss);
   return 0;
 }
 
@@ -206,10 +235,10 @@ int bwd_reduce_t(const void* z, const void* da, int64_t n_pix, int C, const floa
                  const float* beta, float* sums, void* ws, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   if (pick_vec<T>(C, z, da) == N) {
-    BnBwdReduce<T, N> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C};
+    BnBwdReduce<T, N> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C, {}, {}, {}, {}};
     launch_channel_reduce<N>(f, n_pix, C, (float*)ws, sums, st);
   } else {
-    BnBwdReduce<T, 1> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C};
+    BnBwdReduce<T, 1> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C, {}, {}, {}, {}};
     launch_channel_reduce<1>(f, n_pix, C, (float*)ws, sums, st);
   }
   return 0;
@@ -220,22 +249,12 @@ int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, cons
              const float* gamma, const float* beta, const float* sums, float* dbias, void* ws, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = n_pix * C;
-  const size_t lds = (7 * (size_t)C + (size_t)EW_THREADS * N) * sizeof(float);
+  const size_t lds = (size_t)EW_THREADS * N * sizeof(float);
   const float inv_n = (float)(1.0 / (double)n_pix);
   const bool vec = pick_vec<T>(C, z, da, dz) == N;
   const int V = vec ? N : 1;
-  const int CV = C / V;
-  int grid = ew_grid(n / V, EW_THREADS);
-  float* partials = nullptr;
-  if (dbias) {
-    // grid*256 must be a multiple of CV so that a thread keeps one channel vector
-    int g = 1;
-    while ((int64_t)g * EW_THREADS % CV != 0) g++;        // smallest grid unit (CV <= 256*g)
-    grid = (grid / g) * g;
-    if (grid < g) grid = g;
-    if (grid > 1024) grid = (1024 / g) * g > 0 ? (1024 / g) * g : g;
-    partials = (float*)ws;
-  }
+  const int grid = grid_for_fixed_channels(ew_grid(n / V, EW_THREADS), C / V, 1024);
+  float* partials = dbias ? (float*)ws : nullptr;
   if (vec)
     bn_relu_bwd_dz_kernel<T, N><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n,
                                                                  mean_rstd, gamma, beta, sums, partials);

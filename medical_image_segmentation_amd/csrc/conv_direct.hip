@@ -66,6 +66,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
     __syncthreads();
   }
   // persistent walk over 256-pixel groups (trip count is block-uniform: barriers inside are safe)
+#pragma unroll 4
   for (int64_t pix0 = (int64_t)blockIdx.x * CD_THREADS; pix0 < n_pix; pix0 += (int64_t)gridDim.x * CD_THREADS) {
     const int64_t pix = pix0 + tid;
     const bool valid = pix < n_pix;
@@ -159,11 +160,16 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
   for (int t = 0; t < 9; t++)
 #pragma unroll
     for (int j = 0; j < CO_T; j++) acc[t][j] = 0.f;
+  const bool vec_dz = (Cout % CO_T == 0) && (sizeof(T) * CO_T == 16) && (((uintptr_t)dz & 15) == 0);
   for (int64_t pix = p0 + tid; pix < p1; pix += CD_THREADS) {
     const int px = (int)(pix % W), py = (int)((pix / W) % H);
     float g[CO_T];
+    if (vec_dz) {
+      vload<T, CO_T>(dz + pix * Cout + co0, g);
+    } else {
 #pragma unroll
-    for (int j = 0; j < CO_T; j++) g[j] = (co0 + j < Cout) ? to_f32(dz[pix * Cout + co0 + j]) : 0.f;
+      for (int j = 0; j < CO_T; j++) g[j] = (co0 + j < Cout) ? to_f32(dz[pix * Cout + co0 + j]) : 0.f;
+    }
 #pragma unroll
     for (int t = 0; t < 9; t++) {
       const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;

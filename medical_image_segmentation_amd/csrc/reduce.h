@@ -11,7 +11,7 @@
 #include "vec.h"
 
 constexpr int RED_THREADS = 256;
-constexpr int RED_MAX_BLOCKS = 512;
+constexpr int RED_MAX_BLOCKS = 1024;
 
 struct RedPlan {
   int CV, PR, nblk;
@@ -41,6 +41,7 @@ static inline void launch_reduce_partials(const float* partials, int nblk, int n
 }
 
 // F provides:  static constexpr int NOUT;
+//              __device__ void prepare(int c0)          (per-thread channel constants -> registers)
 //              __device__ void load(int64_t pix, int c0, float (&acc)[NOUT][V]) const   (accumulates)
 template <int V, typename F>
 __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(F f, int64_t n_pix, int C, int CV, int PR,
@@ -59,6 +60,8 @@ __global__ __launch_bounds__(RED_THREADS) void channel_reduce_kernel(F f, int64_
   int64_t p1 = p0 + pix_per_blk;
   if (p1 > n_pix) p1 = n_pix;
   if (pr < PR) {
+    f.prepare(cv * V);
+#pragma unroll 4
     for (int64_t p = p0 + pr; p < p1; p += PR) f.load(p, cv * V, acc);
 #pragma unroll
     for (int o = 0; o < NOUT; o++)
