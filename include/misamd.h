@@ -16,6 +16,11 @@
  *   - parameters and their gradients are float32 in the reference's layouts
  *     (conv weight [Cout][Cin][3][3], as nn.Conv2d stores it);
  *   - targets are int64 class indices [B][H][W], counts are int64;
+ *   - "lazy activations": where an argument `X_affine` accompanies an activation
+ *     pointer X, a non-NULL value is a float32 [2][C] table (scale[C] then shift[C])
+ *     and the kernel reads relu(X*scale + shift) instead of X — the BatchNorm + ReLU
+ *     of the layer that produced X, applied on load so that the normalised
+ *     activation is never written to memory.  NULL = X is used as stored;
  *   - every function returns 0 on success or a mis_status; mis_last_error() gives
  *     a thread-local message.  The Python host raises RuntimeError on non-zero,
  *     matching the reference's exception-based error convention.
@@ -90,14 +95,15 @@ int mis_loss_bwd(const void* logits, int dtype, int64_t stride_b, int64_t stride
 /* Down / Up: nn.MaxPool2d(2,2) (model/unet.py:19,48,52,56,60) and             */
 /* nn.Upsample(2,'bilinear',align_corners=True) + torch.cat([up, skip], 1)      */
 /* (model/unet.py:20,66-67,71-72,76-77,80-81).  Channels-last, H and W even.    */
-int mis_maxpool2x2_fwd(const void* x, int dtype, int B, int H, int W, int C, void* y, mis_stream_t stream);
+int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, int H, int W, int C, void* y,
+                       mis_stream_t stream);
 /* dx = gradient routed to the first maximum of each window (row-major scan,    */
 /* strict '>'), zero elsewhere; x is the forward input.                         */
-int mis_maxpool2x2_bwd(const void* x, const void* dy, int dtype, int B, int H, int W, int C,
+int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int B, int H, int W, int C,
                        void* dx, mis_stream_t stream);
 /* out[b][2h][2w][0:Cup] = bilinear(low), out[...][Cup:Cup+Cskip] = skip.        */
-int mis_upsample2x_cat_fwd(const void* low, const void* skip, int dtype, int B, int h, int w,
-                           int Cup, int Cskip, void* out, mis_stream_t stream);
+int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const void* skip, const float* skip_affine,
+                           int dtype, int B, int h, int w, int Cup, int Cskip, void* out, mis_stream_t stream);
 /* dlow[b][h][w][Cup] gathered from dout[..., 0:Cup]; dskip = dout[..., Cup:].   */
 int mis_upsample2x_cat_bwd(const void* dout, int dtype, int B, int h, int w, int Cup, int Cskip,
                            void* dlow, void* dskip, mis_stream_t stream);
@@ -128,15 +134,15 @@ int mis_set_conv_path(int mode);
 /* Cin->Cout) and, with the transposed=1 image and the channel counts swapped,  */
 /* for the data gradient.                                                       */
 size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int mis_conv3x3_fwd(const void* x, const void* w_packed, const float* bias, int dtype,
+int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype,
                     int B, int H, int W, int Cin, int Cout,
                     void* z, float* stats, void* workspace, mis_stream_t stream);
 
 /* dW float32 [Cout][Cin][3][3] = sum_{b,y,x} dz[b,y,x,co] * x[b,y+ky-1,x+kx-1,ci] */
 /* (autograd of nn.Conv2d wrt its weight).  Overwrites dw.                       */
 size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int mis_conv3x3_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout,
-                      float* dw, void* workspace, mis_stream_t stream);
+int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W,
+                      int Cin, int Cout, float* dw, void* workspace, mis_stream_t stream);
 
 /* Training-mode BatchNorm2d statistics -> per-channel affine + running stats.   */
 /* stats float32 [2][C] (sum, sum of squares over n = B*H*W values per channel). */
@@ -176,12 +182,13 @@ int mis_channel_sum(const void* x, int dtype, int64_t n_pix, int C, float* out, 
 /* ------------------------------------------------------------------------- */
 /* Output layer nn.Conv2d(base, n_classes, 1) — model/unet.py:44,84.            */
 /* w float32 [Cout][Cin], bias float32 [Cout].                                   */
-int mis_conv1x1_fwd(const void* x, int dtype, int64_t n_pix, int Cin, int Cout, const float* w,
-                    const float* bias, void* y, mis_stream_t stream);
+int mis_conv1x1_fwd(const void* x, const float* x_affine, int dtype, int64_t n_pix, int Cin, int Cout,
+                    const float* w, const float* bias, void* y, mis_stream_t stream);
 size_t mis_conv1x1_bwd_workspace_bytes(int64_t n_pix, int Cin, int Cout);
 /* dx (same dtype), dw float32 [Cout][Cin], dbias float32 [Cout]; dx may be NULL. */
-int mis_conv1x1_bwd(const void* x, const void* dy, int dtype, int64_t n_pix, int Cin, int Cout,
-                    const float* w, void* dx, float* dw, float* dbias, void* workspace, mis_stream_t stream);
+int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int64_t n_pix, int Cin,
+                    int Cout, const float* w, void* dx, float* dw, float* dbias, void* workspace,
+                    mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Layout / dtype helpers for the model boundary (NCHW float32 images in,       */

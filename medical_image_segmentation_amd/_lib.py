@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmisamd.so")
+LIB_PATH = os.environ.get("MISAMD_LIBRARY") or os.path.join(_HERE, "libmisamd.so")
 
 F32, BF16 = 0, 1
 
@@ -28,17 +28,17 @@ PROTOTYPES = {
     "mis_loss_metrics_fwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_dice_from_sums": (_i, [_vp, _i, _f, _vp, _vp]),
     "mis_loss_bwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
-    "mis_maxpool2x2_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mis_upsample2x_cat_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_upsample2x_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_upsample2x_cat_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mis_conv3x3_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mis_pack_conv3x3_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mis_set_conv_path": (_i, [_i]),
     "mis_conv3x3_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "mis_conv3x3_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mis_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "mis_conv3x3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mis_bn_finalize": (_i, [_vp, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_eval_affine": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     "mis_bn_relu_apply": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
@@ -47,9 +47,9 @@ PROTOTYPES = {
     "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_channel_sum_workspace_bytes": (_sz, [_i64, _i]),
     "mis_channel_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
-    "mis_conv1x1_fwd": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "mis_conv1x1_fwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv1x1_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
-    "mis_conv1x1_bwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_conv1x1_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_nchw_f32_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 

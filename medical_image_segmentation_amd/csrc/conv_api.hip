@@ -56,16 +56,18 @@ size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   return (m > c ? m : c) + 256;
 }
 
-int mis_conv3x3_fwd(const void* x, const void* w_packed, const float* bias, int dtype, int B, int H, int W, int Cin,
-                    int Cout, void* z, float* stats, void* workspace, mis_stream_t stream) {
+int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype, int B,
+                    int H, int W, int Cin, int Cout, void* z, float* stats, void* workspace, mis_stream_t stream) {
   MIS_REQUIRE(x && w_packed && z, "conv3x3_fwd: null pointer");
   MIS_REQUIRE(!stats || workspace, "conv3x3_fwd: stats requested without a workspace");
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_fwd: bad shape");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_fwd: bad dtype %d", dtype);
   MIS_REQUIRE((int64_t)B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < ((int64_t)1 << 40), "conv3x3_fwd: tensor too large");
   if (use_mfma(dtype, Cin, Cout))
-    return conv3x3_mfma_fwd(x, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace, (hipStream_t)stream);
-  return conv3x3_direct_fwd(x, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace, (hipStream_t)stream);
+    return conv3x3_mfma_fwd(x, x_affine, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace,
+                            (hipStream_t)stream);
+  return conv3x3_direct_fwd(x, x_affine, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace,
+                            (hipStream_t)stream);
 }
 
 size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -75,14 +77,14 @@ size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout)
   return (b > c ? b : c) + 256;
 }
 
-int mis_conv3x3_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
-                      void* workspace, mis_stream_t stream) {
+int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W, int Cin,
+                      int Cout, float* dw, void* workspace, mis_stream_t stream) {
   MIS_REQUIRE(x && dz && dw, "conv3x3_wgrad: null pointer");
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_wgrad: bad shape");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_wgrad: bad dtype %d", dtype);
   if (!force_direct() && workspace && conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout))
-    return conv3x3_wgrad_mfma(x, dz, dtype, B, H, W, Cin, Cout, dw, workspace, (hipStream_t)stream);
-  return conv3x3_direct_wgrad(x, dz, dtype, B, H, W, Cin, Cout, dw, (hipStream_t)stream);
+    return conv3x3_wgrad_mfma(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, workspace, (hipStream_t)stream);
+  return conv3x3_direct_wgrad(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, (hipStream_t)stream);
 }
 
 }  // extern "C"

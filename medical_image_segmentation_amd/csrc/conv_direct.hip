@@ -39,7 +39,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
     const T* __restrict__ x, const T* __restrict__ wp /*[9][Cout][Cin]*/, const float* __restrict__ bias,
     T* __restrict__ z, float* __restrict__ partials /*[gridDim.x][2][Cout] or null*/, int B, int H, int W, int Cin,
-    int Cout) {
+    int Cout, const float* __restrict__ in_aff) {
   __shared__ float wl[9][CI_CHUNK][CO_T];
   __shared__ float red[2 * CO_T * (CD_THREADS / 64)];
   const int tid = threadIdx.x;
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
           for (int ci = 0; ci < cn; ci += V) {
             float xv[V];
             vload<T, V>(xp + ci, xv);
+            affine_relu_rounded<T, V>(xv, in_aff, Cin, c0 + ci);
 #pragma unroll
             for (int k = 0; k < V; k++)
 #pragma unroll
@@ -147,7 +148,8 @@ template <typename T>
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const T* __restrict__ x,
                                                                           const T* __restrict__ dz,
                                                                           float* __restrict__ dw, int B, int H, int W,
-                                                                          int Cin, int Cout, int64_t pix_per_blk) {
+                                                                          int Cin, int Cout, int64_t pix_per_blk,
+                                                                          const float* __restrict__ x_aff) {
   __shared__ float red[9 * CO_T * (CD_THREADS / 64)];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int co0 = blockIdx.y * CO_T, ci = blockIdx.z;
@@ -174,8 +176,10 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
     for (int t = 0; t < 9; t++) {
       const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
       float xv = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
         xv = to_f32(x[(pix + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * Cin + ci]);
+        if (x_aff) xv = to_f32(from_f32<T>(fmaxf(xv * x_aff[ci] + x_aff[Cin + ci], 0.f)));
+      }
 #pragma unroll
       for (int j = 0; j < CO_T; j++) acc[t][j] += xv * g[j];
     }
@@ -202,9 +206,15 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
 template <typename T, int V, int CO>
 __global__ __launch_bounds__(CD_THREADS) void conv1x1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, T* __restrict__ y,
-                                                                 int64_t n_pix, int Cin) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cin][CO]  (transposed: ci major)
+                                                                 int64_t n_pix, int Cin,
+                                                                 const float* __restrict__ x_aff) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [Cin][CO]  (transposed: ci major), then [2][Cin]
   for (int i = threadIdx.x; i < Cin * CO; i += CD_THREADS) wl[i] = w[(i % CO) * Cin + i / CO];
+  const float* aff = nullptr;
+  if (x_aff) {
+    for (int i = threadIdx.x; i < 2 * Cin; i += CD_THREADS) wl[Cin * CO + i] = x_aff[i];
+    aff = wl + Cin * CO;
+  }
   __syncthreads();
   float bv[CO];
 #pragma unroll
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_fwd_kernel(const T* __rest
     for (int c = 0; c < Cin; c += V) {
       float xv[V];
       vload<T, V>(x + p * Cin + c, xv);
+      affine_relu<V>(xv, aff, Cin, c);
 #pragma unroll
       for (int k = 0; k < V; k++)
 #pragma unroll
@@ -234,7 +245,8 @@ template <typename T, int V, int CO>
 __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  const float* __restrict__ w, T* __restrict__ dx,
                                                                  float* __restrict__ partials, int64_t n_pix, int Cin,
-                                                                 int64_t pix_per_blk) {
+                                                                 int64_t pix_per_blk,
+                                                                 const float* __restrict__ x_aff) {
   extern __shared__ float red[];                 // [256][CO*V + CO]
   constexpr int NR = CO * V + CO;
   const int tid = threadIdx.x;
@@ -246,6 +258,12 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
   for (int j = 0; j < CO; j++)
 #pragma unroll
     for (int k = 0; k < V; k++) wr[j][k] = w[j * Cin + c0 + k];
+  float asc[V], ash[V];                          // lazy-activation affine of this thread's channels
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    asc[k] = x_aff ? x_aff[c0 + k] : 1.f;
+    ash[k] = x_aff ? x_aff[Cin + c0 + k] : 0.f;
+  }
   float aw[CO][V], ab[CO];
 #pragma unroll
   for (int j = 0; j < CO; j++) {
@@ -260,6 +278,10 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
     float g[CO], xv[V], d[V];
     vload<T, CO>(dy + p * CO, g);
     vload<T, V>(x + p * Cin + c0, xv);
+    if (x_aff) {
+#pragma unroll
+      for (int k = 0; k < V; k++) xv[k] = fmaxf(xv[k] * asc[k] + ash[k], 0.f);
+    }
 #pragma unroll
     for (int k = 0; k < V; k++) d[k] = 0.f;
 #pragma unroll
@@ -306,20 +328,21 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
 constexpr int C1_MAX_BLOCKS = 1024;
 
 template <typename T, int CO>
-int conv1x1_fwd_t(const void* x, int64_t n_pix, int Cin, const float* w, const float* bias, void* y, hipStream_t st) {
+int conv1x1_fwd_t(const void* x, const float* x_aff, int64_t n_pix, int Cin, const float* w, const float* bias,
+                  void* y, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
-  const size_t lds = (size_t)Cin * CO * sizeof(float);
+  const size_t lds = ((size_t)Cin * CO + 2 * (size_t)Cin) * sizeof(float);
   const int grid = ew_grid(n_pix, CD_THREADS);
   if (pick_vec<T>(Cin, x) == N)
-    conv1x1_fwd_kernel<T, N, CO><<<grid, CD_THREADS, lds, st>>>((const T*)x, w, bias, (T*)y, n_pix, Cin);
+    conv1x1_fwd_kernel<T, N, CO><<<grid, CD_THREADS, lds, st>>>((const T*)x, w, bias, (T*)y, n_pix, Cin, x_aff);
   else
-    conv1x1_fwd_kernel<T, 1, CO><<<grid, CD_THREADS, lds, st>>>((const T*)x, w, bias, (T*)y, n_pix, Cin);
+    conv1x1_fwd_kernel<T, 1, CO><<<grid, CD_THREADS, lds, st>>>((const T*)x, w, bias, (T*)y, n_pix, Cin, x_aff);
   return 0;
 }
 
 template <typename T, int CO>
-int conv1x1_bwd_t(const void* x, const void* dy, int64_t n_pix, int Cin, const float* w, void* dx, float* dw,
-                  float* dbias, void* ws, hipStream_t st) {
+int conv1x1_bwd_t(const void* x, const float* x_aff, const void* dy, int64_t n_pix, int Cin, const float* w, void* dx,
+                  float* dw, float* dbias, void* ws, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const bool vec = pick_vec<T>(Cin, x, dx) == N && (CD_THREADS % (Cin / N)) == 0;
   const int V = vec ? N : 1;
@@ -333,10 +356,10 @@ int conv1x1_bwd_t(const void* x, const void* dy, int64_t n_pix, int Cin, const f
   if (vec) {
     auto k = conv1x1_bwd_kernel<T, N, CO>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k<<<nblk, CD_THREADS, lds, st>>>((const T*)x, (const T*)dy, w, (T*)dx, partials, n_pix, Cin, ppb);
+    k<<<nblk, CD_THREADS, lds, st>>>((const T*)x, (const T*)dy, w, (T*)dx, partials, n_pix, Cin, ppb, x_aff);
   } else {
     conv1x1_bwd_kernel<T, 1, CO><<<nblk, CD_THREADS, lds, st>>>((const T*)x, (const T*)dy, w, (T*)dx, partials, n_pix,
-                                                                 Cin, ppb);
+                                                                 Cin, ppb, x_aff);
   }
   launch_reduce_partials(partials, nblk, CO * Cin, dw, st, CO * Cin + CO);
   launch_reduce_partials(partials + CO * Cin, nblk, CO, dbias, st, CO * Cin + CO);
@@ -374,8 +397,8 @@ size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout) {
   return align256((size_t)CD_MAX_BLOCKS * 2 * Cout * sizeof(float));
 }
 
-int conv3x3_direct_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
-                       int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
+int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
+                       int W, int Cin, int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
   const int64_t n_pix = (int64_t)B * H * W;
   int gx = cdiv(n_pix, CD_THREADS);
   if (gx > CD_MAX_BLOCKS) gx = CD_MAX_BLOCKS;
@@ -384,17 +407,17 @@ int conv3x3_direct_fwd(const void* x, const void* wp, const float* bias, int dty
   if (dtype == MIS_F32) {
     if (Cin % 4 == 0 && ((uintptr_t)x % 16) == 0)
       conv3x3_direct_kernel<float, 4><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)wp, bias, (float*)z,
-                                                                    partials, B, H, W, Cin, Cout);
+                                                                    partials, B, H, W, Cin, Cout, in_aff);
     else
       conv3x3_direct_kernel<float, 1><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)wp, bias, (float*)z,
-                                                                    partials, B, H, W, Cin, Cout);
+                                                                    partials, B, H, W, Cin, Cout, in_aff);
   } else {
     if (Cin % 8 == 0 && ((uintptr_t)x % 16) == 0)
       conv3x3_direct_kernel<bf16, 8><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)wp, bias, (bf16*)z,
-                                                                   partials, B, H, W, Cin, Cout);
+                                                                   partials, B, H, W, Cin, Cout, in_aff);
     else
       conv3x3_direct_kernel<bf16, 1><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)wp, bias, (bf16*)z,
-                                                                   partials, B, H, W, Cin, Cout);
+                                                                   partials, B, H, W, Cin, Cout, in_aff);
   }
   MIS_CHECK_LAUNCH("conv3x3_direct_kernel");
   if (stats) {
@@ -421,8 +444,8 @@ int conv3x3_direct_pack(const float* w, int Cw_out, int Cw_in, int transposed, i
   return MIS_OK;
 }
 
-int conv3x3_direct_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
-                         hipStream_t st) {
+int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
+                         int Cout, float* dw, hipStream_t st) {
   const int64_t n_pix = (int64_t)B * H * W;
   if (hipMemsetAsync(dw, 0, (size_t)Cout * Cin * 9 * sizeof(float), st) != hipSuccess) {
     mis_set_error("conv3x3_wgrad: memset failed");
@@ -437,24 +460,24 @@ int conv3x3_direct_wgrad(const void* x, const void* dz, int dtype, int B, int H,
   dim3 grid(nblk, cdiv(Cout, CO_T), Cin);
   if (dtype == MIS_F32)
     conv3x3_wgrad_direct_kernel<float><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)dz, dw, B, H, W, Cin,
-                                                                     Cout, ppb);
+                                                                     Cout, ppb, x_aff);
   else
     conv3x3_wgrad_direct_kernel<bf16><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)dz, dw, B, H, W, Cin,
-                                                                    Cout, ppb);
+                                                                    Cout, ppb, x_aff);
   MIS_CHECK_LAUNCH("conv3x3_wgrad_direct_kernel");
   return MIS_OK;
 }
 
 extern "C" {
 
-int mis_conv1x1_fwd(const void* x, int dtype, int64_t n_pix, int Cin, int Cout, const float* w, const float* bias,
-                    void* y, mis_stream_t stream) {
+int mis_conv1x1_fwd(const void* x, const float* x_affine, int dtype, int64_t n_pix, int Cin, int Cout, const float* w,
+                    const float* bias, void* y, mis_stream_t stream) {
   MIS_REQUIRE(x && w && y && n_pix >= 1 && Cin >= 1, "conv1x1_fwd: bad arguments");
   MIS_REQUIRE(Cout >= 1 && Cout <= 16, "conv1x1_fwd: 1 <= Cout <= 16 required (got %d)", Cout);
   MIS_REQUIRE((size_t)Cin * Cout * 4 <= 48 * 1024, "conv1x1_fwd: Cin*Cout too large");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIS_F32) { DISPATCH_CO(conv1x1_fwd_t, float, Cout, x, n_pix, Cin, w, bias, y, st) }
-  else if (dtype == MIS_BF16) { DISPATCH_CO(conv1x1_fwd_t, bf16, Cout, x, n_pix, Cin, w, bias, y, st) }
+  if (dtype == MIS_F32) { DISPATCH_CO(conv1x1_fwd_t, float, Cout, x, x_affine, n_pix, Cin, w, bias, y, st) }
+  else if (dtype == MIS_BF16) { DISPATCH_CO(conv1x1_fwd_t, bf16, Cout, x, x_affine, n_pix, Cin, w, bias, y, st) }
   else MIS_REQUIRE(false, "conv1x1_fwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("conv1x1_fwd_kernel");
   return MIS_OK;
@@ -464,13 +487,13 @@ size_t mis_conv1x1_bwd_workspace_bytes(int64_t n_pix, int Cin, int Cout) {
   return align256((size_t)C1_MAX_BLOCKS * ((size_t)Cout * Cin + Cout) * sizeof(float));
 }
 
-int mis_conv1x1_bwd(const void* x, const void* dy, int dtype, int64_t n_pix, int Cin, int Cout, const float* w,
-                    void* dx, float* dw, float* dbias, void* workspace, mis_stream_t stream) {
+int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int64_t n_pix, int Cin, int Cout,
+                    const float* w, void* dx, float* dw, float* dbias, void* workspace, mis_stream_t stream) {
   MIS_REQUIRE(x && dy && w && dw && dbias && workspace && n_pix >= 1 && Cin >= 1, "conv1x1_bwd: bad arguments");
   MIS_REQUIRE(Cout >= 1 && Cout <= 16, "conv1x1_bwd: 1 <= Cout <= 16 required (got %d)", Cout);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIS_F32) { DISPATCH_CO(conv1x1_bwd_t, float, Cout, x, dy, n_pix, Cin, w, dx, dw, dbias, workspace, st) }
-  else if (dtype == MIS_BF16) { DISPATCH_CO(conv1x1_bwd_t, bf16, Cout, x, dy, n_pix, Cin, w, dx, dw, dbias, workspace, st) }
+  if (dtype == MIS_F32) { DISPATCH_CO(conv1x1_bwd_t, float, Cout, x, x_affine, dy, n_pix, Cin, w, dx, dw, dbias, workspace, st) }
+  else if (dtype == MIS_BF16) { DISPATCH_CO(conv1x1_bwd_t, bf16, Cout, x, x_affine, dy, n_pix, Cin, w, dx, dw, dbias, workspace, st) }
   else MIS_REQUIRE(false, "conv1x1_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("conv1x1_bwd_kernel");
   return MIS_OK;

@@ -3,10 +3,12 @@
 #include "common.h"
 
 size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout);
-int conv3x3_direct_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
-                       int Cout, void* z, float* stats, void* workspace, hipStream_t st);
-int conv3x3_direct_wgrad(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
-                         hipStream_t st);
+// `in_aff` / `x_aff`: optional [2][Cin] (scale, shift) of a lazily stored input activation:
+// the kernel reads relu(x*scale + shift) instead of x (padding stays zero).
+int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
+                       int W, int Cin, int Cout, void* z, float* stats, void* workspace, hipStream_t st);
+int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
+                         int Cout, float* dw, hipStream_t st);
 
 size_t conv3x3_direct_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_direct_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
@@ -14,11 +16,11 @@ int conv3x3_direct_pack(const float* w, int Cw_out, int Cw_in, int transposed, i
 // Matrix-core path (conv_mfma.hip).  *_supported tell whether the shape is taken.
 bool conv3x3_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
 size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
-int conv3x3_mfma_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
-                     int Cout, void* z, float* stats, void* workspace, hipStream_t st);
+int conv3x3_mfma_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
+                     int W, int Cin, int Cout, void* z, float* stats, void* workspace, hipStream_t st);
 size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
 bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
 size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
-int conv3x3_wgrad_mfma(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
-                       void* workspace, hipStream_t st);
+int conv3x3_wgrad_mfma(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
+                       int Cout, float* dw, void* workspace, hipStream_t st);

@@ -28,14 +28,18 @@
 #include "reduce.h"
 #include <stdlib.h>
 
+#ifndef MIS_DBG
+#define MIS_DBG 0
+#endif
+
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int TW = 16;                   // output tile width; tile height = 4 waves x MT rows
 constexpr int HW_ = TW + 2;              // halo width
 constexpr int CM_THREADS = 256;
 // rows per wave: taller tiles where the register budget allows (narrow Cout, short K chunks)
 constexpr int fwd_mt(int nt, int cpg) { return 4; }   // (8-row variants measured slower: occupancy loss)
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 template <typename T> struct Mf;
 template <> struct Mf<bf16> {
@@ -57,14 +61,26 @@ __device__ __forceinline__ void mfma_step(const f32x4& a, const f32x4& b, f32x4&
 
 constexpr int nsteps_of(int cpg) { return (9 * cpg + 3) / 4; }
 
-// 16-byte slot of (position p, channel group cg) inside the halo image.  With 4 groups per
-// position (64-byte rows) the group index is rotated by 2*(p/4) so that the 16 lanes of one
-// ds_read_b128 service group (16 consecutive positions x one group) hit 16 distinct slots.
-template <int CPG>
-__device__ __forceinline__ int halo_slot(int p, int cg) {
-  if constexpr (CPG == 4) return p * 4 + ((cg + 2 * (p >> 2)) & 3);
-  else return p * CPG + cg;
+// relu(x*scale + shift) on a raw 16-byte channel vector (8 bf16 / 4 f32); sc/sh point at the
+// vector's first channel (LDS).  Used while staging a lazily stored activation.
+template <typename T>
+__device__ __forceinline__ u32x4 affine_relu_raw(u32x4 raw, const float* sc, const float* sh) {
+  constexpr int G = 16 / (int)sizeof(T);
+  union { u32x4 u; T t[G]; } v;
+  v.u = raw;
+#pragma unroll
+  for (int k = 0; k < G; k++) v.t[k] = from_f32<T>(fmaxf(to_f32(v.t[k]) * sc[k] + sh[k], 0.f));
+  return v.u;
 }
+
+// Byte address of (position p, channel group cg) inside the halo image.  A position's row is
+// padded to an odd number of 16-byte groups (16/48/48/80 bytes for 1..4 groups), so the 16
+// lanes of one ds_read_b128 service group (16 consecutive positions, one group) fall into 16
+// distinct bank quads, and every fragment address is lane_base + a compile-time offset.
+template <int CPG>
+constexpr int halo_pstride() { return (CPG | 1) * 16; }
+template <int CPG>
+__device__ __forceinline__ int halo_addr(int p, int cg) { return p * halo_pstride<CPG>() + cg * 16; }
 
 // Packed weight layout: [chunk][step][n-tile (16 couts)][lane 0..63][G elements]; lane l holds
 // W[cout = 16n + (l&15)][k-group 4*step + (l>>4)], group -> (tap, cg) = (g / CPG, g % CPG).
@@ -94,11 +110,37 @@ __global__ void pack_w3x3_frag_kernel(const float* __restrict__ w, int Cw_out, i
   }
 }
 
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// A workgroup walks a CONTIGUOUS range of tiles (x fastest, then y, then image): neighbouring
+// tiles' halos overlap in the same CU's cache, and the tile coordinates advance by carries
+// instead of integer divisions.
+struct TilePos {
+  int tx, ty, b;
+  __device__ __forceinline__ void next(int tiles_x, int tiles_y) {
+    if (++tx == tiles_x) {
+      tx = 0;
+      if (++ty == tiles_y) {
+        ty = 0;
+        ++b;
+      }
+    }
+  }
+};
+
+// Everything a lane needs per stage that does not depend on the tile is computed once, so the
+// per-tile cost of staging is ~4 vector instructions per 16-byte halo element, and the epilogue
+// stores through buffer descriptors with precomputed lane offsets (out-of-range = dropped, so
+// partial tiles and padded channels need no branches).
+// workgroups per CU the register budget is held to: the light variants are latency/HBM-bound
+// and want more waves in flight, the wide ones need the registers
+constexpr int fwd_min_blocks(int nt, int cpg) { return (nt == 4 || nt * cpg >= 6) ? 2 : (nt == 1 && cpg <= 2 ? 4 : 3); }
+
 template <typename T, int NT, int CPG>
-__global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
+__global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_mfma_kernel(
     const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias, T* __restrict__ z,
     float* __restrict__ partials, int B, int H, int W, int Cin, int Cout, int n_chunks, int nt_total, int tiles_x,
-    int tiles_y, int n_tiles) {
+    int tiles_y, int n_tiles, const float* __restrict__ in_aff) {
   constexpr int G = Mf<T>::G;
   using Frag = typename Mf<T>::Frag;
   constexpr int NS = nsteps_of(CPG);
@@ -110,78 +152,128 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
   constexpr int HALO_IT = (HALO_VECS + CM_THREADS - 1) / CM_THREADS;
   constexpr int W_VECS = NS * NT * 64;
   constexpr int W_IT = (W_VECS + CM_THREADS - 1) / CM_THREADS;
+  constexpr bool PAIR = (sizeof(T) == 2 && NT >= 2);   // 16-byte stores from lane pairs (host: Cout % 8 == 0)
+  constexpr int NSTORE = PAIR ? NT / 2 : NT;
+  constexpr unsigned OOB = 0x7FFFFFFFu;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* halo = reinterpret_cast<uint4*>(smem);
-  uint4* wl = halo + HALO_VECS;
+  constexpr int HALO_BYTES = HP * halo_pstride<CPG>() + 16;     // padded rows + 1 dummy slot
+  unsigned char* halo = smem;
+  uint4* wl = reinterpret_cast<uint4*>(smem + HALO_BYTES);
+  float* biasl = reinterpret_cast<float*>(wl + W_VECS);         // [NT*16], zero beyond Cout
+  float* aff = biasl + NT * 16;                                 // [2][Cin] (scale, shift) of a lazy input
   __shared__ float red[4][2][NT * 16];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kg = lane >> 4;
   const int n0 = blockIdx.y * NT;                 // first n-tile of this workgroup
 
   // per-lane tap offsets of each MFMA step (positions inside the halo) and channel group
   // (with 4 groups per position a step is exactly one tap: offsets are compile-time constants)
   constexpr int NTAB = (CPG == 4) ? 1 : NS;
-  int tap_off[NTAB], tap_cg[NTAB];
+  int tap_addr[NTAB];
   if constexpr (CPG != 4) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       int g = 4 * s + kg;
       int tap = g / CPG;
-      tap_cg[s] = g % CPG;
       if (tap > 8) tap = 8;                        // padded group: weights are zero, read finite data
-      tap_off[s] = (tap / 3) * HW_ + (tap % 3);
+      tap_addr[s] = halo_addr<CPG>((tap / 3) * HW_ + (tap % 3), g % CPG);
     }
   }
+  // LDS byte address of this lane's first fragment: wave's first row, lane's column (and group)
+  const int frag_base = halo_addr<CPG>(wid * MT * HW_ + col, CPG == 4 ? kg : 0);
 
-  float s1[NT][4], s2[NT][4];
+  // tile-invariant staging state of this lane's halo elements: kept in registers, except in
+  // the widest variant (no registers to spare) which recomputes it per stage
+  constexpr bool PRE = !(NT == 4 && CPG >= 3);
+  int tid_l = tid;        // laundered per stage when !PRE, so the recomputation is not hoisted (and spilled)
+  auto halo_rel = [&](int i) -> unsigned {      // byte offset of element i relative to the halo origin
+    const int v = tid_l + i * CM_THREADS, pos = v / CPG, cg = v % CPG;
+    return (unsigned)((((pos / HW_) * W + pos % HW_) * Cin + cg * G) * (int)sizeof(T));
+  };
+  auto halo_px = [&](int i) -> int {            // its halo column (huge for tail elements: never loaded)
+    const int v = tid_l + i * CM_THREADS;
+    return v < HALO_VECS ? (v / CPG) % HW_ : (1 << 28);
+  };
+  auto halo_lds = [&](int i) -> int {           // its LDS slot (the dummy slot for tail elements)
+    const int v = tid_l + i * CM_THREADS;
+    return v < HALO_VECS ? halo_addr<CPG>(v / CPG, v % CPG) : HALO_BYTES - 16;
+  };
+  unsigned h_rel[PRE ? HALO_IT : 1];
+  int h_px[PRE ? HALO_IT : 1], h_lds[PRE ? HALO_IT : 1];
+  if constexpr (PRE) {
 #pragma unroll
-  for (int n = 0; n < NT; n++)
+    for (int i = 0; i < HALO_IT; i++) {
+      h_rel[i] = halo_rel(i);
+      h_px[i] = halo_px(i);
+      h_lds[i] = halo_lds(i);
+    }
+  }
+  // lane offsets of the epilogue stores inside the tile (bytes), OOB for padded channels
+  unsigned z_rel[NSTORE];
 #pragma unroll
-    for (int r = 0; r < 4; r++) s1[n][r] = s2[n][r] = 0.f;
+  for (int j = 0; j < NSTORE; j++) {
+    int co;
+    if constexpr (PAIR) co = (n0 + 2 * j) * 16 + ((kg & 1) ? 16 + 4 * (kg - 1) : 4 * kg);
+    else co = (n0 + j) * 16 + 4 * kg;
+    z_rel[j] = (co < Cout) ? (unsigned)((((wid * MT) * W + col) * Cout + co) * (int)sizeof(T)) : OOB;
+  }
+  const unsigned z_row = (unsigned)(W * Cout * (int)sizeof(T));
+
+  f32x4 s1[NT], s2[NT];
+#pragma unroll
+  for (int n = 0; n < NT; n++) s1[n] = s2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 hreg[HALO_IT], wreg[W_IT];
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, n_chunks * NS * nt_total * 1024, 0x00020000);
 
   // Global loads go through buffer descriptors: an out-of-range offset returns zeros in
-  // hardware, which implements the conv's zero padding (and the tail guards) without a branch
-  // or a select on the loaded value — so the loads stay in flight under the MFMAs.
-  constexpr int OOB = 0x7FFFFFFF;
+  // hardware.  Rows above/below the image fall out of the per-image descriptor by themselves
+  // (negative or too-large offsets); only the column needs a compare.  This implements the
+  // conv's zero padding without a branch or a select on the loaded value, so the loads stay in
+  // flight under the MFMAs.  A dead stage (past the last tile) shifts x far left: nothing loads.
   const int img_bytes = H * W * Cin * (int)sizeof(T);
-#define LOAD_HALO(TILE, CHUNK, LIVE)                                                                     \
+#define LOAD_HALO(P, CHUNK, LIVE)                                                                        \
   {                                                                                                      \
-    const bool live_ = (LIVE);                                                                           \
-    const int t_ = live_ ? (TILE) : 0;                                                                   \
-    const int tx_ = t_ % tiles_x, ty_ = (t_ / tiles_x) % tiles_y, b_ = t_ / (tiles_x * tiles_y);         \
-    const int y0_ = ty_ * TH - 1, x0_ = tx_ * TW - 1;                                                    \
+    const int xo_ = (P).tx * TW - 1, yo_ = (P).ty * TH - 1;                                              \
+    const int x0_ = ((LIVE) && !(MIS_DBG & 4)) ? xo_ : -(1 << 29);                                       \
+    const unsigned base_ = (unsigned)(((yo_ * W + xo_) * Cin + (CHUNK) * KC) * (int)sizeof(T));          \
     const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                \
-        (void*)(x + (int64_t)b_ * H * W * Cin), 0, img_bytes, 0x00020000);                               \
+        (void*)(x + (int64_t)(P).b * H * W * Cin), 0, img_bytes, 0x00020000);                            \
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
-      const int v = tid + i * CM_THREADS;                                                                \
-      const int pos = v / CPG, cg = v % CPG;                                                             \
-      const int gy = y0_ + pos / HW_, gx = x0_ + pos % HW_;                                              \
-      const bool ok = live_ && (v < HALO_VECS) && gy >= 0 && gy < H && gx >= 0 && gx < W;                \
-      const int off = ((gy * W + gx) * Cin + (CHUNK) * KC + cg * G) * (int)sizeof(T);                    \
-      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : OOB, 0, 0);                        \
+      const bool ok = (unsigned)(x0_ + (PRE ? h_px[PRE ? i : 0] : halo_px(i))) < (unsigned)W;            \
+      const unsigned rel_ = PRE ? h_rel[PRE ? i : 0] : halo_rel(i);                                      \
+      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(ok ? base_ + rel_ : OOB), 0, 0);        \
     }                                                                                                    \
   }
-#define STORE_HALO()                                                                                     \
+  // STORE_HALO(P, CHUNK): registers -> LDS.  For a lazily stored input the BatchNorm affine and
+  // ReLU of the producing layer are applied here, to in-image positions only (padding stays 0).
+#define STORE_HALO(P, CHUNK)                                                                             \
   {                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
-      const int v = tid + i * CM_THREADS;                                                                \
-      if (v < HALO_VECS) *reinterpret_cast<u32x4*>(&halo[halo_slot<CPG>(v / CPG, v % CPG)]) = hreg[i];   \
+      u32x4 val = hreg[i];                                                                               \
+      if (in_aff) {                                                                                      \
+        const int v = tid + i * CM_THREADS;                                                              \
+        const int pos = v / CPG, cg = v % CPG;                                                           \
+        const int gy = (P).ty * TH - 1 + pos / HW_, gx = (P).tx * TW - 1 + pos % HW_;                    \
+        const int c = (CHUNK) * KC + cg * G;                                                             \
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)                                    \
+          val = affine_relu_raw<T>(val, aff + c, aff + Cin + c);                                         \
+      }                                                                                                  \
+      *reinterpret_cast<u32x4*>(halo + (PRE ? h_lds[PRE ? i : 0] : halo_lds(i))) = val;                  \
     }                                                                                                    \
   }
 #define LOAD_W(CHUNK, LIVE)                                                                              \
   {                                                                                                      \
     const bool live_ = (LIVE);                                                                           \
     _Pragma("unroll") for (int i = 0; i < W_IT; i++) {                                                   \
-      const int v = tid + i * CM_THREADS;                                                                \
+      const int v = tid_l + i * CM_THREADS;                                                              \
       const int s_ = v / (NT * 64), rem = v % (NT * 64);                                                 \
       const int off = ((((CHUNK) * NS + s_) * nt_total + n0) * 64 + rem) * 16;                           \
-      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (live_ && v < W_VECS) ? off : OOB, 0, 0);     \
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (live_ && v < W_VECS) ? off : (int)OOB, 0, 0); \
     }                                                                                                    \
   }
 #define STORE_W()                                                                                        \
@@ -191,144 +283,177 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
       if (v < W_VECS) *reinterpret_cast<u32x4*>(&wl[v]) = wreg[i];                                       \
     }                                                                                                    \
   }
-
-  const bool w_resident = (n_chunks == 1);
-  int tile = blockIdx.x;
-  LOAD_HALO(tile, 0, tile < n_tiles)
-  LOAD_W(0, tile < n_tiles)
-  bool first = true;
-  for (; tile < n_tiles; tile += gridDim.x) {
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-      for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int chunk = 0; chunk < n_chunks; chunk++) {
-      __syncthreads();                     // every wave is done reading the previous stage
-      STORE_HALO()
-      if (!w_resident || first) STORE_W()
-      first = false;
-      __syncthreads();
-      // issue the next stage's global loads; they complete under the MFMAs below
-      {
-        int nchunk = chunk + 1, ntile = tile;
-        if (nchunk == n_chunks) {
-          nchunk = 0;
-          ntile = tile + gridDim.x;
-        }
-        // unconditional issue (dead stages read out of range = zeros): no control flow between
-        // the loads and the MFMAs, so nothing forces an early wait on them
-        LOAD_HALO(ntile, nchunk, ntile < n_tiles)
-        LOAD_W(nchunk, !w_resident && ntile < n_tiles)
-      }
-#pragma unroll
-      for (int s = 0; s < NS; s++) {
-        Frag xa[MT], wf[NT];
-#pragma unroll
-        for (int m = 0; m < MT; m++) {
-          int p = (wid * MT + m) * HW_ + col, cg;
-          if constexpr (CPG == 4) {
-            p += (s / 3) * HW_ + (s % 3);
-            cg = kg;
-          } else {
-            p += tap_off[s];
-            cg = tap_cg[s];
-          }
-          xa[m] = *reinterpret_cast<const Frag*>(&halo[halo_slot<CPG>(p, cg)]);
-        }
-#pragma unroll
-        for (int n = 0; n < NT; n++) wf[n] = *reinterpret_cast<const Frag*>(&wl[(s * NT + n) * 64 + lane]);
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-          for (int m = 0; m < MT; m++) mfma_step(wf[n], xa[m], acc[m][n]);
-      }
-    }
-
-    // epilogue: bias, channels-last store (4 consecutive channels per lane), statistics
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int gx = tx * TW + col;
-    float bv[NT][4];                       // re-read per tile (L1/L2 hit) rather than held in registers
-#pragma unroll
-    for (int n = 0; n < NT; n++) {
-      const int co = (n0 + n) * 16 + 4 * kg;
-      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (bias && co < Cout) b4 = *reinterpret_cast<const f32x4*>(bias + co);
-#pragma unroll
-      for (int r = 0; r < 4; r++) bv[n][r] = b4[r];
-    }
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-      const int gy = ty * TH + wid * MT + m;
-      const bool pv = (gy < H) && (gx < W);
-      T* zp = z + (((int64_t)b * H + gy) * W + gx) * Cout;
-      if constexpr (sizeof(T) == 2 && NT >= 2) {
-        // bf16, >= 32 channels: lanes (kg, kg^1) of a pixel swap halves of a tile pair so every lane
-        // stores 16 bytes = 8 consecutive channels, and the 4 lanes of a pixel one contiguous 64 bytes
-#pragma unroll
-        for (int n = 0; n < NT; n += 2) {
-          float va[4], vb[4];
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            va[r] = acc[m][n][r] + bv[n][r];
-            vb[r] = acc[m][n + 1][r] + bv[n + 1][r];
-          }
-          const int coa = (n0 + n) * 16 + 4 * kg, cob = coa + 16;
-          if (pv && coa < Cout) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              s1[n][r] += va[r];
-              s2[n][r] += va[r] * va[r];
-            }
-          }
-          if (pv && cob < Cout) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              s1[n + 1][r] += vb[r];
-              s2[n + 1][r] += vb[r] * vb[r];
-            }
-          }
-          union { bf16 h[4]; unsigned int u[2]; } pa, pb;
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            pa.h[r] = from_f32<bf16>(va[r]);
-            pb.h[r] = from_f32<bf16>(vb[r]);
-          }
-          const bool odd = kg & 1;
-          // even kg keeps tile n and receives the partner's tile n; odd kg keeps tile n+1
-          const unsigned int s0 = odd ? pa.u[0] : pb.u[0], s1x = odd ? pa.u[1] : pb.u[1];
-          const unsigned int r0 = __shfl_xor(s0, 16, WAVE), r1 = __shfl_xor(s1x, 16, WAVE);
-          u32x4 out;
-          if (!odd) out = u32x4{pa.u[0], pa.u[1], r0, r1};      // channels 4kg .. 4kg+7 of tile n
-          else out = u32x4{r0, r1, pb.u[0], pb.u[1]};           // channels 4(kg-1) .. 4(kg-1)+7 of tile n+1
-          const int co = odd ? (cob - 4) : coa;
-          if (pv && co + 7 < Cout && (Cout & 7) == 0) *reinterpret_cast<u32x4*>(zp + co) = out;
-          else if (pv) {
-            // ragged channel tail (Cout not a multiple of 8 inside this pair): 4-channel stores
-            if (coa < Cout) vstore<T, 4>(zp + coa, va);
-            if (cob < Cout) vstore<T, 4>(zp + cob, vb);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int n = 0; n < NT; n++) {
-          const int co = (n0 + n) * 16 + 4 * kg;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; r++) v[r] = acc[m][n][r] + bv[n][r];
-          if (pv && co < Cout) {
-            vstore<T, 4>(zp + co, v);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              s1[n][r] += v[r];
-              s2[n][r] += v[r] * v[r];
-            }
-          }
-        }
-      }
-    }
+  // EPILOGUE(): store z channels-last and accumulate the statistics.  The accumulators
+  // already hold the bias (they start from it).  A lane owns 4 consecutive channels of a pixel
+  // per n-tile; in bf16 with >= 2 n-tiles, lane rows (kg, kg^1) exchange halves of a tile pair
+  // (one v_permlane16_swap per register) so every lane stores 16 bytes = 8 consecutive channels.
+#define EPILOGUE()                                                                                       \
+  {                                                                                                      \
+    bool pvm[MT];                                                                                        \
+    _Pragma("unroll") for (int m = 0; m < MT; m++) pvm[m] = true;                                        \
+    if (!(live && (cur.ty * TH + TH <= H) && (cur.tx * TW + TW <= W))) {                                 \
+      /* partial tile (or the leading load-only iteration): pixels outside contribute nothing */         \
+      _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                   \
+        pvm[m] = live && (cur.ty * TH + wid * MT + m < H) && (cur.tx * TW + col < W);                    \
+        if (!pvm[m]) {                                                                                   \
+          _Pragma("unroll") for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};          \
+        }                                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
+    if (partials) {                                                                                      \
+      _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                   \
+        _Pragma("unroll") for (int n = 0; n < NT; n++) {                                                 \
+          s1[n] += acc[m][n];                                                                            \
+          s2[n] += acc[m][n] * acc[m][n];                                                                \
+        }                                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
+    const __amdgpu_buffer_rsrc_t zrs_ = __builtin_amdgcn_make_buffer_rsrc(                               \
+        (void*)(z + (int64_t)cur.b * H * W * Cout), 0, H * W * Cout * (int)sizeof(T), 0x00020000);       \
+    const unsigned zb_ = (unsigned)(((cur.ty * TH * W) + cur.tx * TW) * Cout * (int)sizeof(T));          \
+    _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                     \
+      const unsigned zm_ = zb_ + (unsigned)m * z_row;                                                    \
+      _Pragma("unroll") for (int j = 0; j < NSTORE; j++) {                                               \
+        const int off_ = (int)((pvm[m] && !(MIS_DBG & 1)) ? zm_ + z_rel[j] : OOB);                       \
+        if constexpr (PAIR) {                                                                            \
+          union { bf16 h[4]; unsigned int u[2]; } pa, pb;                                                \
+          _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                \
+            pa.h[r] = from_f32<bf16>(acc[m][2 * j][r]);                                                  \
+            pb.h[r] = from_f32<bf16>(acc[m][2 * j + 1][r]);                                              \
+          }                                                                                              \
+          const u32x2 q0 = __builtin_amdgcn_permlane16_swap(pa.u[0], pb.u[0], false, false);             \
+          const u32x2 q1 = __builtin_amdgcn_permlane16_swap(pa.u[1], pb.u[1], false, false);             \
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{q0[0], q1[0], q0[1], q1[1]}, zrs_, off_, 0, 0);   \
+        } else if constexpr (sizeof(T) == 2) {                                                           \
+          union { bf16 h[4]; u32x2 u; } pa;                                                              \
+          _Pragma("unroll") for (int r = 0; r < 4; r++) pa.h[r] = from_f32<bf16>(acc[m][j][r]);          \
+          __builtin_amdgcn_raw_buffer_store_b64(pa.u, zrs_, off_, 0, 0);                                 \
+        } else {                                                                                         \
+          union { f32x4 f; u32x4 u; } pa;                                                                \
+          pa.f = acc[m][j];                                                                              \
+          __builtin_amdgcn_raw_buffer_store_b128(pa.u, zrs_, off_, 0, 0);                                \
+        }                                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
   }
+
+  for (int i = tid; i < NT * 16; i += CM_THREADS) {
+    const int co = n0 * 16 + i;
+    biasl[i] = (bias && co < Cout) ? bias[co] : 0.f;
+  }
+  if (in_aff) {
+    for (int i = tid; i < 2 * Cin; i += CM_THREADS) aff[i] = in_aff[i];     // visible after the first barrier below
+  }
+  // this workgroup's contiguous tile range
+  const int nb_ = gridDim.x, q_ = n_tiles / nb_, r_ = n_tiles % nb_;
+  const int bx = blockIdx.x;
+  const int t_begin = bx * q_ + (bx < r_ ? bx : r_);
+  const int t_count = q_ + (bx < r_ ? 1 : 0);
+  TilePos cur;
+  cur.tx = t_begin % tiles_x;
+  cur.ty = (t_begin / tiles_x) % tiles_y;
+  cur.b = t_begin / (tiles_x * tiles_y);
+
+  // Weights that fit one chunk stay in LDS for the whole kernel.  With fewer than 4 groups per
+  // position that is always so and they are staged here, once; otherwise (runtime chunk count)
+  // they travel through the stage pipeline below.
+  constexpr bool W_ONCE = (CPG < 4);
+  const bool w_resident = (n_chunks == 1);
+  if constexpr (W_ONCE) {
+    LOAD_W(0, true)
+    STORE_W()                               // visible after the first barrier of the tile loop
+  }
+  bool first = true;
+
+#define LOAD_FRAGS(S, BUF)                                                                               \
+  {                                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                     \
+      int a_;                                                                                            \
+      if constexpr (CPG == 4) a_ = frag_base + halo_addr<CPG>(m * HW_ + ((S) / 3) * HW_ + ((S) % 3), 0); \
+      else a_ = frag_base + tap_addr[CPG == 4 ? 0 : (S)] + halo_addr<CPG>(m * HW_, 0);                   \
+      xa[BUF][m] = *reinterpret_cast<const Frag*>(halo + a_);                                            \
+    }                                                                                                    \
+    _Pragma("unroll") for (int n = 0; n < NT; n++)                                                       \
+      wf[BUF][n] = *reinterpret_cast<const Frag*>(&wl[((S) * NT + n) * 64 + lane]);                      \
+  }
+  // One stage = one (tile, 32-channel chunk): halo (+ weights) registers -> LDS, issue the next
+  // stage's global loads, then the MFMAs.  The loads are issued unconditionally (dead stages
+  // read out of range = zeros).  FIRST_CHUNK: the accumulators start from the bias.
+#define STAGE(CHUNK, FIRST_CHUNK)                                                                        \
+  {                                                                                                      \
+    if (live) {                                                                                          \
+      __syncthreads(); /* every wave is done reading the previous stage */                               \
+      if constexpr (!PRE) asm volatile("" : "+v"(tid_l));                                                \
+      STORE_HALO(cur, (CHUNK))                                                                           \
+      if constexpr (!W_ONCE) {                                                                           \
+        if (!w_resident || first) STORE_W()                                                              \
+        first = false;                                                                                   \
+      }                                                                                                  \
+      __syncthreads();                                                                                   \
+    }                                                                                                    \
+    if constexpr (!PRE) asm volatile("" : "+v"(tid_l));                                                  \
+    if ((CHUNK) + 1 < nch) {                                                                             \
+      LOAD_HALO(cur, (CHUNK) + 1, true)                                                                  \
+      if constexpr (!W_ONCE) LOAD_W((CHUNK) + 1, true)                                                   \
+    } else {                                                                                             \
+      LOAD_HALO(nxt, 0, it + 1 < t_count)                                                                \
+      if constexpr (!W_ONCE) LOAD_W(0, (!w_resident || !live) && it + 1 < t_count)                       \
+    }                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0); /* loads stay ahead of the MFMAs (the scheduler would sink them) */ \
+    if (live) {                                                                                          \
+      if (FIRST_CHUNK) {                                                                                 \
+        _Pragma("unroll") for (int n = 0; n < NT; n++) {                                                 \
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(&biasl[n * 16 + 4 * kg]);                     \
+          _Pragma("unroll") for (int m = 0; m < MT; m++) acc[m][n] = b4;                                 \
+        }                                                                                                \
+      }                                                                                                  \
+      Frag xa[2][MT], wf[2][NT];                                                                         \
+      if constexpr (NT < 4) {                                                                            \
+        /* fragments of step s+1 are fetched from LDS while the MFMAs of step s run (two register */     \
+        /* sets); the scheduling barrier keeps the compiler from hoisting every step's reads up */       \
+        LOAD_FRAGS(0, 0)                                                                                 \
+        _Pragma("unroll") for (int s = 0; s < ((MIS_DBG & 8) ? 1 : NS); s++) {                           \
+          if (s + 1 < NS) LOAD_FRAGS(s + 1, (s + 1) & 1)                                                 \
+          _Pragma("unroll") for (int n = 0; n < NT; n++)                                                 \
+            _Pragma("unroll") for (int m = 0; m < MT; m++)                                               \
+              mfma_step(wf[s & 1][n], xa[s & 1][m], acc[m][n]);                                          \
+          __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                \
+      } else {                                                                                           \
+        /* widest variants: one fragment set, the compiler interleaves reads and MFMAs itself */         \
+        _Pragma("unroll") for (int s = 0; s < NS; s++) {                                                 \
+          LOAD_FRAGS(s, 0)                                                                               \
+          _Pragma("unroll") for (int n = 0; n < NT; n++)                                                 \
+            _Pragma("unroll") for (int m = 0; m < MT; m++) mfma_step(wf[0][n], xa[0][m], acc[m][n]);     \
+        }                                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+  // The loop runs one extra, leading iteration (it = -1) that only issues the first tile's
+  // loads and an epilogue whose stores are all out of range.  No load is in flight when the
+  // loop is entered, so every path into a tile's first wait has the same shape — loads, then
+  // an epilogue's stores — and the wait the compiler derives covers the loads only: a tile
+  // does not wait for the previous tile's stores to be acknowledged (the counter retires in
+  // order and the stores are younger than the loads).
+  TilePos nxt = cur;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = -1; it < t_count; it++) {
+    const bool live = it >= 0;
+    const int nch = live ? n_chunks : 1;
+    if (live) nxt.next(tiles_x, tiles_y);
+    // the first chunk is peeled: its wait sits behind an epilogue's stores, the others' do not
+    STAGE(0, true)
+    for (int chunk = 1; chunk < nch; chunk++) STAGE(chunk, false)
+    EPILOGUE()
+    cur = nxt;
+  }
+#undef STAGE
+#undef LOAD_FRAGS
 
   if (partials) {
     // sum over the 16 pixel lanes that share a channel quad, then over the 4 waves
@@ -361,6 +486,7 @@ __global__ __launch_bounds__(CM_THREADS, 2) void conv3x3_mfma_kernel(
 #undef STORE_HALO
 #undef LOAD_W
 #undef STORE_W
+#undef EPILOGUE
 
 struct FwdPlan {
   int CPG, NT, n_chunks, nt_total, grid_x, grid_y, tiles_x, tiles_y, n_tiles;
@@ -384,6 +510,7 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
   p.nt_total = (Cout + 15) / 16;
   p.NT = p.nt_total >= 4 ? 4 : (p.nt_total >= 2 ? 2 : 1);
   if (p.nt_total % p.NT != 0) p.NT = (p.nt_total % 2 == 0) ? 2 : 1;
+  if (sizeof(T) == 2 && Cout % 8 != 0) p.NT = 1;      // the paired 16-byte stores need whole 8-channel groups
   p.grid_y = p.nt_total / p.NT;
   const int TH = 4 * fwd_mt(p.NT, p.CPG);
   p.tiles_x = (W + TW - 1) / TW;
@@ -399,35 +526,36 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
   if (gx < 256) gx = 256;
   if (gx > p.n_tiles) gx = p.n_tiles;
   p.grid_x = gx;
-  p.lds = (size_t)(TH + 2) * HW_ * p.CPG * 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024;
+  p.lds = (size_t)(TH + 2) * HW_ * ((p.CPG | 1) * 16) + 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
+          (size_t)p.NT * 16 * 4 + 2 * (size_t)Cin * 4;
   return true;
 }
 
 template <typename T, int NT, int CPG>
-void launch_fwd_k(const FwdPlan& p, const void* x, const void* wp, const float* bias, void* z, float* partials, int B,
-                  int H, int W, int Cin, int Cout, hipStream_t st) {
+void launch_fwd_k(const FwdPlan& p, const void* x, const float* in_aff, const void* wp, const float* bias, void* z,
+                  float* partials, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
   auto kfn = conv3x3_mfma_kernel<T, NT, CPG>;
   if (p.lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
   kfn<<<dim3(p.grid_x, p.grid_y), CM_THREADS, p.lds, st>>>(
       (const T*)x, (const T*)wp, bias, (T*)z, partials, B, H, W, Cin, Cout, p.n_chunks, p.nt_total, p.tiles_x,
-      p.tiles_y, p.n_tiles);
+      p.tiles_y, p.n_tiles, in_aff);
 }
 
 template <typename T, int NT>
-void launch_fwd_cpg(const FwdPlan& p, const void* x, const void* wp, const float* bias, void* z, float* partials,
-                    int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+void launch_fwd_cpg(const FwdPlan& p, const void* x, const float* in_aff, const void* wp, const float* bias, void* z,
+                    float* partials, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
   switch (p.CPG) {
-    case 1: launch_fwd_k<T, NT, 1>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    case 2: launch_fwd_k<T, NT, 2>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    case 3: launch_fwd_k<T, NT, 3>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    default: launch_fwd_k<T, NT, 4>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 1: launch_fwd_k<T, NT, 1>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 2: launch_fwd_k<T, NT, 2>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 3: launch_fwd_k<T, NT, 3>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    default: launch_fwd_k<T, NT, 4>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
   }
 }
 
 template <typename T>
-int run_fwd(const void* x, const void* wp, const float* bias, int B, int H, int W, int Cin, int Cout, void* z,
-            float* stats, void* workspace, hipStream_t st) {
+int run_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int B, int H, int W, int Cin, int Cout,
+            void* z, float* stats, void* workspace, hipStream_t st) {
   FwdPlan p;
   if (!plan_fwd<T>(B, H, W, Cin, Cout, p)) {
     mis_set_error("conv3x3_mfma: unsupported shape Cin=%d Cout=%d", Cin, Cout);
@@ -435,9 +563,9 @@ int run_fwd(const void* x, const void* wp, const float* bias, int B, int H, int 
   }
   float* partials = stats ? (float*)workspace : nullptr;
   switch (p.NT) {
-    case 1: launch_fwd_cpg<T, 1>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    case 2: launch_fwd_cpg<T, 2>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    default: launch_fwd_cpg<T, 4>(p, x, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 1: launch_fwd_cpg<T, 1>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 2: launch_fwd_cpg<T, 2>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    default: launch_fwd_cpg<T, 4>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
   }
   MIS_CHECK_LAUNCH("conv3x3_mfma_kernel");
   if (stats) {
@@ -483,10 +611,10 @@ int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int
   return MIS_OK;
 }
 
-int conv3x3_mfma_fwd(const void* x, const void* wp, const float* bias, int dtype, int B, int H, int W, int Cin,
-                     int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
-  if (dtype == MIS_BF16) return run_fwd<bf16>(x, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
-  return run_fwd<float>(x, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
+int conv3x3_mfma_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
+                     int W, int Cin, int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
+  if (dtype == MIS_BF16) return run_fwd<bf16>(x, in_aff, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
+  return run_fwd<float>(x, in_aff, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
 }
 
 // =====================================================================================
@@ -545,7 +673,8 @@ template <typename T, int MTO, int NTI, int WCO, int WCI, int WK>
 __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dz,
                                                                  float* __restrict__ slab, int B, int H, int W,
                                                                  int Cin, int Cout, int n_ci_blocks, int tiles_x,
-                                                                 int tiles_y, int n_tiles) {
+                                                                 int tiles_y, int n_tiles,
+                                                                 const float* __restrict__ x_aff) {
   constexpr int NTHR = 64 * WCO * WCI * WK;
   constexpr int G = Mf<T>::G;
   constexpr int TH = WgT<T>::TH;
@@ -561,6 +690,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xh = smem;                      // [PH] rows of RSX bytes (CTI channels + pad)
   unsigned char* zt = smem + PH * RSX;           // [PZ] rows of RSZ bytes
+  float* aff = reinterpret_cast<float*>(zt + PZ * RSZ);   // [2][CTI] (scale, shift) of this block's x channels
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid % WK, wci = (wid / WK) % WCI, wco = wid / (WK * WCI);
@@ -608,12 +738,20 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel
           zrs_, ok ? ((gy * W + gx) * Cout + c) * (int)sizeof(T) : OOB, 0, 0);                          \
     }                                                                                                   \
   }
-#define WG_STORE()                                                                                      \
+#define WG_STORE(TILE)                                                                                  \
   {                                                                                                     \
+    const int t_ = (TILE);                                                                              \
+    const int y0_ = ((t_ / tiles_x) % tiles_y) * TH - 1, x0_ = (t_ % tiles_x) * WG_TW - 1;              \
     _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                   \
-      const int v = tid + i * NTHR;                                                                      \
+      const int v = tid + i * NTHR;                                                                     \
       const int pos = v / XVP, cv = v % XVP;                                                            \
-      if (v < XV) *reinterpret_cast<u32x4*>(xh + pos * RSX + cv * 16) = xr[i];                          \
+      u32x4 val = xr[i];                                                                                \
+      if (x_aff) {                                                                                      \
+        const int gy = y0_ + pos / HWW, gx = x0_ + pos % HWW;                                           \
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W && ci0 + cv * G < Cin)                               \
+          val = affine_relu_raw<T>(val, aff + cv * G, aff + CTI + cv * G);                              \
+      }                                                                                                 \
+      if (v < XV) *reinterpret_cast<u32x4*>(xh + pos * RSX + cv * 16) = val;                            \
     }                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < ZIT; i++) {                                                   \
       const int v = tid + i * NTHR;                                                                      \
@@ -627,11 +765,17 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel
   const int offx = k_pixel(lg, 0, lq) * RSX + 8 * lp + wci * NTI * 32;
   const int offz = k_pixel(lg, 0, lq) * RSZ + 8 * lp + wco * MTO * 32;
 
+  if (x_aff) {
+    for (int i = tid; i < 2 * CTI; i += NTHR) {
+      const int c = ci0 + i % CTI;
+      aff[i] = (c < Cin) ? x_aff[(i / CTI) * Cin + c] : 0.f;
+    }
+  }
   int tile = blockIdx.x;
   WG_LOAD(tile, tile < n_tiles)
   for (; tile < n_tiles; tile += gridDim.x) {
     __syncthreads();
-    WG_STORE()
+    WG_STORE(tile)
     __syncthreads();
     WG_LOAD(tile + (int)gridDim.x, tile + (int)gridDim.x < n_tiles)
 
@@ -790,7 +934,7 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p) {
   if (ns < 1) ns = 1;
   p.nsplit = ns;
   const size_t tiles = (size_t)(TH + 2) * (WG_TW + 2) * padded_row_bytes(p.CTI * (int)sizeof(T)) +
-                       (size_t)TH * WG_TW * padded_row_bytes(p.CTO * (int)sizeof(T));
+                       (size_t)TH * WG_TW * padded_row_bytes(p.CTO * (int)sizeof(T)) + 2 * (size_t)p.CTI * 4;
   // K-split reduction scratch: one 9 x (tiles per wave) x 1 KiB region per (co,ci) wave group
   const size_t redb = (size_t)9 * (p.CTO / 16) * (p.CTI / 16) * 64 * 16;
   p.lds = tiles > redb ? tiles : redb;
@@ -798,8 +942,8 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p) {
 }
 
 template <typename T>
-int run_wgrad(const void* x, const void* dz, int B, int H, int W, int Cin, int Cout, float* dw, void* workspace,
-              hipStream_t st) {
+int run_wgrad(const void* x, const float* x_aff, const void* dz, int B, int H, int W, int Cin, int Cout, float* dw,
+              void* workspace, hipStream_t st) {
   WgPlan p;
   if (!plan_wgrad<T>(B, H, W, Cin, Cout, p)) {
     mis_set_error("conv3x3_wgrad_mfma: unsupported shape Cin=%d Cout=%d", Cin, Cout);
@@ -813,7 +957,7 @@ int run_wgrad(const void* x, const void* dz, int B, int H, int W, int Cin, int C
     if (p.lds > 48 * 1024)                                                                                 \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
     kfn<<<grid, 64 * WCO * WCI * WK, p.lds, st>>>((const T*)x, (const T*)dz, slab, B, H, W, Cin, Cout,     \
-                                                  p.n_ci_blocks, p.tiles_x, p.tiles_y, p.n_tiles);         \
+                                                  p.n_ci_blocks, p.tiles_x, p.tiles_y, p.n_tiles, x_aff);  \
   }
   switch (p.cfg) {
     case 0: WG_LAUNCH(1, 1, 1, 1, 4); break;
@@ -849,8 +993,8 @@ size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Ci
   return align256((size_t)p.nsplit * 9 * Cin * Cout * sizeof(float));
 }
 
-int conv3x3_wgrad_mfma(const void* x, const void* dz, int dtype, int B, int H, int W, int Cin, int Cout, float* dw,
-                       void* workspace, hipStream_t st) {
-  if (dtype == MIS_BF16) return run_wgrad<bf16>(x, dz, B, H, W, Cin, Cout, dw, workspace, st);
-  return run_wgrad<float>(x, dz, B, H, W, Cin, Cout, dw, workspace, st);
+int conv3x3_wgrad_mfma(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
+                       int Cout, float* dw, void* workspace, hipStream_t st) {
+  if (dtype == MIS_BF16) return run_wgrad<bf16>(x, x_aff, dz, B, H, W, Cin, Cout, dw, workspace, st);
+  return run_wgrad<float>(x, x_aff, dz, B, H, W, Cin, Cout, dw, workspace, st);
 }

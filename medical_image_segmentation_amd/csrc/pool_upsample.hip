@@ -17,7 +17,15 @@ constexpr int EW_THREADS = 256;
 
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                                 int B, int H, int W, int C) {
+                                                                 int B, int H, int W, int C,
+                                                                 const float* __restrict__ in_aff) {
+  extern __shared__ float aff_lds[];
+  const float* aff = nullptr;
+  if (in_aff) {
+    for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) aff_lds[i] = in_aff[i];
+    __syncthreads();
+    aff = aff_lds;
+  }
   const int Ho = H >> 1, Wo = W >> 1, CV = C / V;
   const int64_t total = (int64_t)B * Ho * Wo * CV;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
@@ -33,6 +41,10 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __rest
     vload<T, V>(src + C, v01);
     vload<T, V>(src + (int64_t)W * C, v10);
     vload<T, V>(src + (int64_t)W * C + C, v11);
+    affine_relu<V>(v00, aff, C, cv * V);
+    affine_relu<V>(v01, aff, C, cv * V);
+    affine_relu<V>(v10, aff, C, cv * V);
+    affine_relu<V>(v11, aff, C, cv * V);
 #pragma unroll
     for (int k = 0; k < V; k++) {
       float mm = v00[k];
@@ -47,7 +59,15 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __rest
 
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                                 T* __restrict__ dx, int B, int H, int W, int C) {
+                                                                 T* __restrict__ dx, int B, int H, int W, int C,
+                                                                 const float* __restrict__ in_aff) {
+  extern __shared__ float aff_lds[];
+  const float* aff = nullptr;
+  if (in_aff) {
+    for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) aff_lds[i] = in_aff[i];
+    __syncthreads();
+    aff = aff_lds;
+  }
   const int Ho = H >> 1, Wo = W >> 1, CV = C / V;
   const int64_t total = (int64_t)B * Ho * Wo * CV;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
@@ -64,6 +84,8 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __rest
     vload<T, V>(src + C, v[1]);
     vload<T, V>(src + (int64_t)W * C, v[2]);
     vload<T, V>(src + (int64_t)W * C + C, v[3]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) affine_relu<V>(v[j], aff, C, cv * V);
     vload<T, V>(dy + i * V, g);
 #pragma unroll
     for (int k = 0; k < V; k++) {
@@ -99,7 +121,20 @@ __device__ __forceinline__ void up_taps(int dst, float scale, int n_in, int& i0,
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void upcat_fwd_kernel(const T* __restrict__ low, const T* __restrict__ skip,
                                                                T* __restrict__ out, int B, int h, int w, int Cup,
-                                                               int Cskip, float sy, float sx) {
+                                                               int Cskip, float sy, float sx,
+                                                               const float* __restrict__ low_aff,
+                                                               const float* __restrict__ skip_aff) {
+  extern __shared__ float aff_lds[];              // [2][Cup] then [2][Cskip]
+  const float *affl = nullptr, *affs = nullptr;
+  if (low_aff) {
+    for (int i = threadIdx.x; i < 2 * Cup; i += EW_THREADS) aff_lds[i] = low_aff[i];
+    affl = aff_lds;
+  }
+  if (skip_aff) {
+    for (int i = threadIdx.x; i < 2 * Cskip; i += EW_THREADS) aff_lds[2 * Cup + i] = skip_aff[i];
+    affs = aff_lds + 2 * Cup;
+  }
+  if (low_aff || skip_aff) __syncthreads();
   const int Ho = 2 * h, Wo = 2 * w, Ct = Cup + Cskip, CV = Ct / V, CVup = Cup / V;
   const int64_t total = (int64_t)B * Ho * Wo * CV;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
@@ -121,10 +156,15 @@ __global__ __launch_bounds__(EW_THREADS) void upcat_fwd_kernel(const T* __restri
       vload<T, V>(base + ((int64_t)y0 * w + x1) * Cup, bq);
       vload<T, V>(base + ((int64_t)y1 * w + x0) * Cup, c);
       vload<T, V>(base + ((int64_t)y1 * w + x1) * Cup, d);
+      affine_relu<V>(a, affl, Cup, cv * V);
+      affine_relu<V>(bq, affl, Cup, cv * V);
+      affine_relu<V>(c, affl, Cup, cv * V);
+      affine_relu<V>(d, affl, Cup, cv * V);
 #pragma unroll
       for (int k = 0; k < V; k++) r[k] = hy0 * (wx0 * a[k] + wx1 * bq[k]) + hy1 * (wx0 * c[k] + wx1 * d[k]);
     } else {
       vload<T, V>(skip + (((int64_t)b * Ho + yo) * Wo + xo) * Cskip + (cv - CVup) * V, r);
+      affine_relu<V>(r, affs, Cskip, (cv - CVup) * V);
     }
     vstore<T, V>(out + i * V, r);
   }
@@ -207,44 +247,47 @@ __global__ __launch_bounds__(EW_THREADS) void slice_channels_kernel(const T* __r
 }
 
 template <typename T>
-int pool_fwd(const void* x, void* y, int B, int H, int W, int C, hipStream_t st) {
+int pool_fwd(const void* x, void* y, int B, int H, int W, int C, const float* aff, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
+  const size_t lds = aff ? 2 * (size_t)C * sizeof(float) : 0;
   if (pick_vec<T>(C, x, y) == N)
-    maxpool_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, 0, st>>>((const T*)x, (T*)y, B, H, W, C);
+    maxpool_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (T*)y, B, H, W, C, aff);
   else
-    maxpool_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, 0, st>>>((const T*)x, (T*)y, B, H, W, C);
+    maxpool_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (T*)y, B, H, W, C, aff);
   return 0;
 }
 
 template <typename T>
-int pool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, hipStream_t st) {
+int pool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, const float* aff, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
+  const size_t lds = aff ? 2 * (size_t)C * sizeof(float) : 0;
   if (pick_vec<T>(C, x, dy, dx) == N)
-    maxpool_bwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, 0, st>>>((const T*)x, (const T*)dy, (T*)dx, B,
-                                                                                  H, W, C);
+    maxpool_bwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (T*)dx,
+                                                                                    B, H, W, C, aff);
   else
-    maxpool_bwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, 0, st>>>((const T*)x, (const T*)dy, (T*)dx, B, H,
-                                                                              W, C);
+    maxpool_bwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (T*)dx, B, H,
+                                                                                W, C, aff);
   return 0;
 }
 
 inline float up_scale(int n_in) { return (2 * n_in > 1) ? (float)(n_in - 1) / (float)(2 * n_in - 1) : 0.f; }
 
 template <typename T>
-int upcat_fwd(const void* low, const void* skip, void* out, int B, int h, int w, int Cup, int Cskip, hipStream_t st) {
+int upcat_fwd(const void* low, const void* skip, void* out, int B, int h, int w, int Cup, int Cskip,
+              const float* low_aff, const float* skip_aff, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int Ct = Cup + Cskip;
   const int64_t n = (int64_t)B * 4 * h * w * Ct;
   const bool vec = (Cup % N == 0) && (Cskip % N == 0) && pick_vec<T>(Ct, low, skip, out) == N;
+  const size_t lds = (low_aff || skip_aff) ? 2 * (size_t)Ct * sizeof(float) : 0;
   if (vec)
-    upcat_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, 0, st>>>((const T*)low, (const T*)skip, (T*)out,
-                                                                                B, h, w, Cup, Cskip, up_scale(h),
-                                                                                up_scale(w));
+    upcat_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>(
+        (const T*)low, (const T*)skip, (T*)out, B, h, w, Cup, Cskip, up_scale(h), up_scale(w), low_aff, skip_aff);
   else
-    upcat_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, 0, st>>>((const T*)low, (const T*)skip, (T*)out, B,
-                                                                            h, w, Cup, Cskip, up_scale(h), up_scale(w));
+    upcat_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>(
+        (const T*)low, (const T*)skip, (T*)out, B, h, w, Cup, Cskip, up_scale(h), up_scale(w), low_aff, skip_aff);
   return 0;
 }
 
@@ -275,35 +318,41 @@ int upcat_bwd(const void* dout, void* dlow, void* dskip, int B, int h, int w, in
 
 extern "C" {
 
-int mis_maxpool2x2_fwd(const void* x, int dtype, int B, int H, int W, int C, void* y, mis_stream_t stream) {
+int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, int H, int W, int C, void* y,
+                       mis_stream_t stream) {
   MIS_REQUIRE(x && y, "maxpool2x2_fwd: null pointer");
   MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
               "maxpool2x2_fwd: H and W must be even and >= 2 (got %dx%d)", H, W);
-  if (dtype == MIS_F32) pool_fwd<float>(x, y, B, H, W, C, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) pool_fwd<bf16>(x, y, B, H, W, C, (hipStream_t)stream);
+  MIS_REQUIRE(C <= 4096, "maxpool2x2_fwd: C too large");
+  if (dtype == MIS_F32) pool_fwd<float>(x, y, B, H, W, C, x_affine, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) pool_fwd<bf16>(x, y, B, H, W, C, x_affine, (hipStream_t)stream);
   else MIS_REQUIRE(false, "maxpool2x2_fwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("maxpool_fwd_kernel");
   return MIS_OK;
 }
 
-int mis_maxpool2x2_bwd(const void* x, const void* dy, int dtype, int B, int H, int W, int C, void* dx,
-                       mis_stream_t stream) {
+int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int B, int H, int W, int C,
+                       void* dx, mis_stream_t stream) {
   MIS_REQUIRE(x && dy && dx, "maxpool2x2_bwd: null pointer");
   MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
               "maxpool2x2_bwd: H and W must be even and >= 2 (got %dx%d)", H, W);
-  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx, B, H, W, C, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx, B, H, W, C, (hipStream_t)stream);
+  MIS_REQUIRE(C <= 4096, "maxpool2x2_bwd: C too large");
+  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx, B, H, W, C, x_affine, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx, B, H, W, C, x_affine, (hipStream_t)stream);
   else MIS_REQUIRE(false, "maxpool2x2_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("maxpool_bwd_kernel");
   return MIS_OK;
 }
 
-int mis_upsample2x_cat_fwd(const void* low, const void* skip, int dtype, int B, int h, int w, int Cup, int Cskip,
-                           void* out, mis_stream_t stream) {
+int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const void* skip, const float* skip_affine,
+                           int dtype, int B, int h, int w, int Cup, int Cskip, void* out, mis_stream_t stream) {
   MIS_REQUIRE(low && out && (skip || Cskip == 0), "upsample2x_cat_fwd: null pointer");
   MIS_REQUIRE(B >= 1 && h >= 1 && w >= 1 && Cup >= 1 && Cskip >= 0, "upsample2x_cat_fwd: bad shape");
-  if (dtype == MIS_F32) upcat_fwd<float>(low, skip, out, B, h, w, Cup, Cskip, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) upcat_fwd<bf16>(low, skip, out, B, h, w, Cup, Cskip, (hipStream_t)stream);
+  MIS_REQUIRE(Cup + Cskip <= 4096, "upsample2x_cat_fwd: too many channels");
+  if (dtype == MIS_F32)
+    upcat_fwd<float>(low, skip, out, B, h, w, Cup, Cskip, low_affine, skip_affine, (hipStream_t)stream);
+  else if (dtype == MIS_BF16)
+    upcat_fwd<bf16>(low, skip, out, B, h, w, Cup, Cskip, low_affine, skip_affine, (hipStream_t)stream);
   else MIS_REQUIRE(false, "upsample2x_cat_fwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("upcat_fwd_kernel");
   return MIS_OK;

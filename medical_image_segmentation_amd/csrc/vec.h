@@ -43,6 +43,27 @@ __device__ __forceinline__ void vstore(T* __restrict__ p, const float (&v)[N]) {
   }
 }
 
+// Lazy activations: a tensor may be stored as the pre-BatchNorm conv output z together with a
+// per-channel affine (scale, shift); its value is relu(z*scale + shift), applied by whoever
+// loads it.  `aff` is a [2][C] table (scale then shift), normally staged in LDS; null = plain.
+template <int V>
+__device__ __forceinline__ void affine_relu(float (&v)[V], const float* aff, int C, int c0) {
+  if (aff) {
+#pragma unroll
+    for (int k = 0; k < V; k++) v[k] = fmaxf(v[k] * aff[c0 + k] + aff[C + c0 + k], 0.f);
+  }
+}
+
+// Same, rounded to the storage type T: the convolutions use the activation as a T operand on
+// every path (matrix-core and vector-ALU), so they all see identical values.
+template <typename T, int V>
+__device__ __forceinline__ void affine_relu_rounded(float (&v)[V], const float* aff, int C, int c0) {
+  if (aff) {
+#pragma unroll
+    for (int k = 0; k < V; k++) v[k] = to_f32(from_f32<T>(fmaxf(v[k] * aff[c0 + k] + aff[C + c0 + k], 0.f)));
+  }
+}
+
 // Picks the widest channel vector (full 16 B, else scalar) that divides C and keeps alignment.
 template <typename T>
 static inline int pick_vec(int C, const void* a, const void* b = nullptr, const void* c = nullptr,

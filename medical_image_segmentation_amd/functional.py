@@ -136,28 +136,32 @@ def pack_weights(w, dtype, transposed=False):
     return out
 
 
-def conv3x3_raw(x, w_packed, bias, Cout, want_stats):
-    """z = conv3x3(x) + bias; optionally the per-channel (sum, sumsq) of z."""
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None):
+    """z = conv3x3(act(x)) + bias; optionally the per-channel (sum, sumsq) of z.
+    act(x) = relu(x*scale + shift) when x_ss ([2, Cin]) is given (lazy activation), else x."""
     B, Cin, H, W = x.shape
     z = _empty_act(B, Cout, H, W, x)
     stats = torch.empty((2, Cout), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Cout), x.device)
     es = x.element_size()
     with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, (B * H * W * (Cin + Cout) + 9 * Cin * Cout) * es):
-        call("mis_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
-             _dt(x), B, H, W, Cin, Cout, z.data_ptr(), stats.data_ptr() if want_stats else None, ws.data_ptr(),
-             _stream())
+        call("mis_conv3x3_fwd", x.data_ptr(), _p(x_ss), w_packed.data_ptr(), _p(bias),
+             _dt(x), B, H, W, Cin, Cout, z.data_ptr(), _p(stats), ws.data_ptr(), _stream())
     return z, stats
 
 
-def conv3x3_wgrad_raw(x, dz):
+def conv3x3_wgrad_raw(x, dz, x_ss=None):
     B, Cin, H, W = x.shape
     Cout = dz.shape[1]
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
     ws = workspace(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), x.device)
     with _prof("conv3x3_wgrad", 18 * B * H * W * Cin * Cout,
                B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout):
-        call("mis_conv3x3_wgrad", x.data_ptr(), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout, dw.data_ptr(),
+        call("mis_conv3x3_wgrad", x.data_ptr(), _p(x_ss), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout, dw.data_ptr(),
              ws.data_ptr(), _stream())
     return dw
 
@@ -175,8 +179,13 @@ def channel_sum_raw(x):
 # Conv3x3 + BatchNorm2d + ReLU   (model/utils/modules.py:86-94)
 # ---------------------------------------------------------------------------
 class ConvBnReluFn(torch.autograd.Function):
+    """(x, x_ss) -> (z, ss): the activation relu(bn(conv(act(x)))) in LAZY form — the conv output z
+    plus the BatchNorm affine ss = [scale, shift]; consumers apply relu(z*scale + shift) when they
+    load it, so the normalised activation is never written to memory.  The gradient that flows
+    into `z` is the gradient with respect to the ACTIVATION."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps, momentum):
+    def forward(ctx, x, x_ss, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps, momentum):
         _check_act(x)
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
@@ -184,7 +193,7 @@ class ConvBnReluFn(torch.autograd.Function):
             raise ValueError(f"weight {tuple(weight.shape)} does not match input channels {Cin}")
         n_pix = B * H * W
         wf = pack_weights(weight.detach(), x.dtype)
-        z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout, training)
+        z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout, training, x_ss)
         ss = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         mr = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         st = _stream()
@@ -192,25 +201,21 @@ class ConvBnReluFn(torch.autograd.Function):
             if n_pix <= 1:
                 raise ValueError("Expected more than 1 value per channel when training")
             call("mis_bn_finalize", stats.data_ptr(), Cout, n_pix, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
-                 running_mean.data_ptr() if running_mean is not None else None,
-                 running_var.data_ptr() if running_var is not None else None,
-                 nbt.data_ptr() if nbt is not None else None, ss.data_ptr(), mr.data_ptr(), st)
+                 _p(running_mean), _p(running_var), _p(nbt), ss.data_ptr(), mr.data_ptr(), st)
         else:
             call("mis_bn_eval_affine", running_mean.data_ptr(), running_var.data_ptr(), gamma.data_ptr(),
                  beta.data_ptr(), Cout, eps, ss.data_ptr(), st)
             mr[0].copy_(running_mean)
             mr[1].copy_(torch.rsqrt(running_var + eps))
-        a = _empty_act(B, Cout, H, W, x)
-        with _prof("bn_relu_apply", 0, 2 * z.numel() * z.element_size()):
-            call("mis_bn_relu_apply", z.data_ptr(), _dt(x), n_pix, Cout, ss.data_ptr(), a.data_ptr(), st)
-        ctx.save_for_backward(x, z, weight, gamma, beta, mr)
+        ctx.save_for_backward(x, x_ss, z, weight, gamma, beta, mr)
         ctx.training = training
         ctx.has_bias = bias is not None
-        return a
+        ctx.mark_non_differentiable(ss)
+        return z, ss
 
     @staticmethod
-    def backward(ctx, da):
-        x, z, weight, gamma, beta, mr = ctx.saved_tensors
+    def backward(ctx, da, _dss):
+        x, x_ss, z, weight, gamma, beta, mr = ctx.saved_tensors
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
         n_pix = B * H * W
@@ -225,24 +230,44 @@ class ConvBnReluFn(torch.autograd.Function):
         # eval mode: statistics are constants, so the two projection terms vanish
         proj = sums if ctx.training else torch.zeros_like(sums)
         dz = torch.empty_like(z)
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
         dbias = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
         with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
             call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
-                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
-                 dbias.data_ptr() if want_db else None, ws.data_ptr(), st)
+                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(), _p(dbias), ws.data_ptr(), st)
         dx = None
         if ctx.needs_input_grad[0]:
             wd = pack_weights(weight.detach(), x.dtype, transposed=True)
             dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
-        dw = conv3x3_wgrad_raw(x, dz) if ctx.needs_input_grad[1] else None
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
+        dw = conv3x3_wgrad_raw(x, dz, x_ss) if ctx.needs_input_grad[2] else None
+        return dx, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
-def conv_bn_relu(x, conv, bn, training):
-    """x -> relu(bn(conv(x))) with the parameters of an nn.Conv2d / nn.BatchNorm2d pair."""
+class MaterializeFn(torch.autograd.Function):
+    """Lazy activation (z, ss) -> the plain tensor relu(z*scale + shift).  Identity in activation
+    space, so the backward passes the gradient through unchanged."""
+
+    @staticmethod
+    def forward(ctx, z, ss):
+        B, Cc, H, W = z.shape
+        a = torch.empty_like(z)
+        with _prof("bn_relu_apply", 0, 2 * z.numel() * z.element_size()):
+            call("mis_bn_relu_apply", z.data_ptr(), _dt(z), B * H * W, Cc, ss.data_ptr(), a.data_ptr(), _stream())
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        return da, None
+
+
+def materialize(t, ss):
+    return t if ss is None else MaterializeFn.apply(t, ss)
+
+
+def conv_bn_relu(x, x_ss, conv, bn, training):
+    """(x, x_ss) -> lazy (z, ss) with the parameters of an nn.Conv2d / nn.BatchNorm2d pair."""
     momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
-    return ConvBnReluFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+    return ConvBnReluFn.apply(x, x_ss, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                               bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum))
 
 
@@ -251,33 +276,35 @@ def conv_bn_relu(x, conv, bn, training):
 # ---------------------------------------------------------------------------
 class MaxPool2x2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, x_ss):
         _check_act(x)
         B, Cc, H, W = x.shape
         if H % 2 or W % 2:
             raise ValueError(f"max-pool 2x2 needs even H and W, got {H}x{W}")
         y = _empty_act(B, Cc, H // 2, W // 2, x)
         with _prof("maxpool2x2_fwd", 0, (x.numel() + y.numel()) * x.element_size()):
-            call("mis_maxpool2x2_fwd", x.data_ptr(), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
-        ctx.save_for_backward(x)
+            call("mis_maxpool2x2_fwd", x.data_ptr(), _p(x_ss), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
+        ctx.save_for_backward(x, x_ss)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x, x_ss = ctx.saved_tensors
         B, Cc, H, W = x.shape
         dy = to_act(dy, x.dtype)
         dx = torch.empty_like(x)
         with _prof("maxpool2x2_bwd", 0, (2 * x.numel() + dy.numel()) * x.element_size()):
-            call("mis_maxpool2x2_bwd", x.data_ptr(), dy.data_ptr(), _dt(x), B, H, W, Cc, dx.data_ptr(), _stream())
-        return dx
+            call("mis_maxpool2x2_bwd", x.data_ptr(), _p(x_ss), dy.data_ptr(), _dt(x), B, H, W, Cc, dx.data_ptr(),
+                 _stream())
+        return dx, None
 
 
 class UpsampleCatFn(torch.autograd.Function):
-    """cat([bilinear_x2(low), skip], dim=1) — upsampled channels first (unet.py:66-67)."""
+    """cat([bilinear_x2(low), skip], dim=1) — upsampled channels first (unet.py:66-67); either
+    input may be a lazy activation."""
 
     @staticmethod
-    def forward(ctx, low, skip):
+    def forward(ctx, low, low_ss, skip, skip_ss):
         _check_act(low, "low")
         _check_act(skip, "skip")
         B, Cup, h, w = low.shape
@@ -286,8 +313,8 @@ class UpsampleCatFn(torch.autograd.Function):
             raise ValueError(f"skip {tuple(skip.shape)} does not match upsampled {(B, Cup, 2 * h, 2 * w)}")
         out = _empty_act(B, Cup + Cskip, 2 * h, 2 * w, low)
         with _prof("upsample2x_cat_fwd", 0, (low.numel() + skip.numel() + out.numel()) * low.element_size()):
-            call("mis_upsample2x_cat_fwd", low.data_ptr(), skip.data_ptr(), _dt(low), B, h, w, Cup, Cskip,
-                 out.data_ptr(), _stream())
+            call("mis_upsample2x_cat_fwd", low.data_ptr(), _p(low_ss), skip.data_ptr(), _p(skip_ss), _dt(low), B, h, w,
+                 Cup, Cskip, out.data_ptr(), _stream())
         ctx.dims = (B, h, w, Cup, Cskip)
         return out
 
@@ -300,28 +327,28 @@ class UpsampleCatFn(torch.autograd.Function):
         with _prof("upsample2x_cat_bwd", 0, (dout.numel() + dlow.numel() + dskip.numel()) * dout.element_size()):
             call("mis_upsample2x_cat_bwd", dout.data_ptr(), _dt(dout), B, h, w, Cup, Cskip, dlow.data_ptr(),
                  dskip.data_ptr(), _stream())
-        return dlow, dskip
+        return dlow, None, dskip, None
 
 
 class Conv1x1Fn(torch.autograd.Function):
-    """nn.Conv2d(Cin, n_classes, 1) — unet.py:44,84."""
+    """nn.Conv2d(Cin, n_classes, 1) — unet.py:44,84; the input may be a lazy activation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, x_ss, weight, bias):
         _check_act(x)
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
         y = _empty_act(B, Cout, H, W, x)
         with _prof("conv1x1_fwd", 2 * B * H * W * Cin * Cout, (x.numel() + y.numel()) * x.element_size()):
-            call("mis_conv1x1_fwd", x.data_ptr(), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
-                 bias.data_ptr() if bias is not None else None, y.data_ptr(), _stream())
-        ctx.save_for_backward(x, weight)
+            call("mis_conv1x1_fwd", x.data_ptr(), _p(x_ss), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
+                 _p(bias), y.data_ptr(), _stream())
+        ctx.save_for_backward(x, x_ss, weight)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, x_ss, weight = ctx.saved_tensors
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
         dy = to_act(dy, x.dtype)
@@ -330,9 +357,9 @@ class Conv1x1Fn(torch.autograd.Function):
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
         ws = workspace(query("mis_conv1x1_bwd_workspace_bytes", B * H * W, Cin, Cout), x.device)
         with _prof("conv1x1_bwd", 4 * B * H * W * Cin * Cout, (2 * x.numel() + dy.numel()) * x.element_size()):
-            call("mis_conv1x1_bwd", x.data_ptr(), dy.data_ptr(), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
-                 dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream())
-        return dx, dw, (db if ctx.has_bias else None)
+            call("mis_conv1x1_bwd", x.data_ptr(), _p(x_ss), dy.data_ptr(), _dt(x), B * H * W, Cin, Cout,
+                 weight.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream())
+        return dx, None, dw, (db if ctx.has_bias else None)
 
 
 # ---------------------------------------------------------------------------

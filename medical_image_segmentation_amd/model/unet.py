@@ -62,18 +62,28 @@ class UNet(nn.Module):
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
         down, upcat = F_.MaxPool2x2Fn.apply, F_.UpsampleCatFn.apply
+        drop = self._drop
         x = F_.to_act(x, self._dtype())
-        x1 = self.encoder1(x)
-        x2 = self.encoder2(self._drop(self.encoder_dropout1, down(x1)))
-        x3 = self.encoder3(self._drop(self.encoder_dropout2, down(x2)))
-        x4 = self.encoder4(self._drop(self.encoder_dropout3, down(x3)))
-        x5 = self._drop(self.encoder_dropout4, down(x4))
-        y = self._drop(self.bottleneck_dropout, self.center_conv(x5))
-        y = self._drop(self.decoder_dropout1, self.decoder1(upcat(y, x4)))
-        y = self._drop(self.decoder_dropout2, self.decoder2(upcat(y, x3)))
-        y = self.decoder3(upcat(y, x2))
-        y = self.decoder4(upcat(y, x1))
-        return F_.Conv1x1Fn.apply(y, self.out_conv.weight, self.out_conv.bias)
+        # every DoubleConv output stays lazy (z, ss): pool, upsample+concat, the next conv and the
+        # 1x1 head apply its BatchNorm affine + ReLU while loading it
+        z1, s1 = self.encoder1.forward_lazy(x)
+        z2, s2 = self.encoder2.forward_lazy(drop(self.encoder_dropout1, down(z1, s1)))
+        z3, s3 = self.encoder3.forward_lazy(drop(self.encoder_dropout2, down(z2, s2)))
+        z4, s4 = self.encoder4.forward_lazy(drop(self.encoder_dropout3, down(z3, s3)))
+        x5 = drop(self.encoder_dropout4, down(z4, s4))
+        y, sy = self._lazy_drop(self.bottleneck_dropout, *self.center_conv.forward_lazy(x5))
+        y, sy = self._lazy_drop(self.decoder_dropout1, *self.decoder1.forward_lazy(upcat(y, sy, z4, s4)))
+        y, sy = self._lazy_drop(self.decoder_dropout2, *self.decoder2.forward_lazy(upcat(y, sy, z3, s3)))
+        y, sy = self.decoder3.forward_lazy(upcat(y, sy, z2, s2))
+        y, sy = self.decoder4.forward_lazy(upcat(y, sy, z1, s1))
+        return F_.Conv1x1Fn.apply(y, sy, self.out_conv.weight, self.out_conv.bias)
+
+    @staticmethod
+    def _lazy_drop(layer, z, ss):
+        """Dropout on a lazy activation: identity at p == 0 / eval; otherwise materialise first."""
+        if layer.p == 0 or not layer.training:
+            return z, ss
+        return layer(F_.materialize(z, ss)), None
 
     def elastic_net(self, l1_lambda, l2_lambda):
         l1_loss = 0

@@ -37,10 +37,16 @@ class DoubleConv(nn.Module):
             self.relu)
         self._initialize_weights()
 
+    def forward_lazy(self, x, x_ss=None):
+        """(x, x_ss) -> (z, ss): both convs read their input through the producer's BatchNorm
+        affine + ReLU on load; the block's own output stays lazy (conv output + affine)."""
+        z1, ss1 = F_.conv_bn_relu(x, x_ss, self.cbr1[0], self.cbr1[1], self.training)
+        return F_.conv_bn_relu(z1, ss1, self.cbr2[0], self.cbr2[1], self.training)
+
     def forward(self, x):
-        """x: channels-last activation (float32 or bfloat16) on the GPU."""
-        x = F_.conv_bn_relu(x, self.cbr1[0], self.cbr1[1], self.training)
-        return F_.conv_bn_relu(x, self.cbr2[0], self.cbr2[1], self.training)
+        """x: [B, C, H, W] tensor on the GPU (float32 or bfloat16) -> the block's activation."""
+        z, ss = self.forward_lazy(F_.to_act(x))
+        return F_.materialize(z, ss)
 
     def _initialize_weights(self, init_gain=0.02):
         _init_like_reference(self)

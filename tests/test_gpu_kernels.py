@@ -51,6 +51,21 @@ def q(a, dtype):
     return t.to(dtype).to(torch.float32)
 
 
+def lazy_pair(C, seed):
+    """A BatchNorm-like per-channel affine [2, C] (both signs of scale) for lazy inputs."""
+    sc = dg.hash_uniform((C,), seed, 0.4, 1.6) * np.where(dg.hash_uniform((C,), seed + 1, 0, 1) < 0.25, -1.0, 1.0)
+    sh = dg.hash_uniform((C,), seed + 2, -0.5, 0.5)
+    return T(np.stack([sc, sh]).astype(np.float32))
+
+
+def lazy_value(z, ss, dtype):
+    """relu(z*scale + shift) of a lazy activation, from the dtype-rounded z; one rounding to
+    float32 like the kernels' fused multiply-add."""
+    zq = q(z, dtype).double()
+    a = zq * ss[0].double()[None, :, None, None] + ss[1].double()[None, :, None, None]
+    return torch.relu(a).float()
+
+
 # ---------------------------------------------------------------------------
 # loss + metrics
 # ---------------------------------------------------------------------------
@@ -180,7 +195,7 @@ def test_maxpool_golden_and_ties(F_, golden, dtype):
     x[0, 0, :4, :4] = 0.5
     gy = dg.hash_normalish((2, 3, 4, 6), 32)
     xd = act(x, dtype).requires_grad_(True)
-    y = F_.MaxPool2x2Fn.apply(xd)
+    y = F_.MaxPool2x2Fn.apply(xd, None)
     y.backward(act(gy, dtype))
     xo = q(x, dtype).requires_grad_(True)
     yo = orc.maxpool2x2(xo)
@@ -194,16 +209,26 @@ def test_maxpool_golden_and_ties(F_, golden, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 8, 16, 24), (1, 32, 64, 64), (3, 5, 6, 10)])
-def test_maxpool_random(F_, dtype, shape):
-    x = np.maximum(dg.hash_normalish(shape, 301), 0)      # post-ReLU: many exact-zero ties
+@pytest.mark.parametrize("lazy", [False, True])
+def test_maxpool_random(F_, dtype, shape, lazy):
+    """Plain input, and a lazy input (z, ss) whose value relu(z*scale+shift) is formed on load;
+    the gradient returned is the one with respect to that value."""
     gy = dg.hash_normalish((shape[0], shape[1], shape[2] // 2, shape[3] // 2), 302)
+    if lazy:
+        x = dg.hash_normalish(shape, 301)
+        ss = lazy_pair(shape[1], 310)
+        xo = lazy_value(x, ss, dtype).requires_grad_(True)
+        ssd = ss.to(DEV)
+    else:
+        x = np.maximum(dg.hash_normalish(shape, 301), 0)      # post-ReLU: many exact-zero ties
+        xo = q(x, dtype).requires_grad_(True)
+        ssd = None
     xd = act(x, dtype).requires_grad_(True)
-    y = F_.MaxPool2x2Fn.apply(xd)
+    y = F_.MaxPool2x2Fn.apply(xd, ssd)
     y.backward(act(gy, dtype))
-    xo = q(x, dtype).requires_grad_(True)
     yo = orc.maxpool2x2(xo)
     yo.backward(q(gy, dtype))
-    assert torch.equal(y.float().cpu(), yo.detach())
+    assert torch.equal(y.float().cpu(), q(yo.detach(), dtype))
     assert torch.equal(xd.grad.float().cpu(), xo.grad)
 
 
@@ -215,7 +240,7 @@ def test_upsample_cat_golden(F_, golden, dtype):
         skip = dg.hash_normalish((2, 2, 2 * h, 2 * w), 43 + h)
         gy = dg.hash_normalish((2, 5, 2 * h, 2 * w), 53 + h)
         xd, sd = act(x, dtype).requires_grad_(True), act(skip, dtype).requires_grad_(True)
-        y = F_.UpsampleCatFn.apply(xd, sd)
+        y = F_.UpsampleCatFn.apply(xd, None, sd, None)
         y.backward(act(gy, dtype))
         tol = TOL[dtype]
         if dtype == torch.float32:
@@ -231,19 +256,25 @@ def test_upsample_cat_golden(F_, golden, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 16, 8, 8, 8), (1, 64, 16, 16, 32), (2, 8, 4, 6, 24)])
-def test_upsample_cat_random(F_, dtype, shape):
+@pytest.mark.parametrize("lazy", [(False, False), (True, True), (True, False), (False, True)])
+def test_upsample_cat_random(F_, dtype, shape, lazy):
+    """Either input plain or lazy (value relu(z*scale+shift) formed on load)."""
     B, Cup, h, w, Cs = shape
     x = dg.hash_normalish((B, Cup, h, w), 401)
     skip = dg.hash_normalish((B, Cs, 2 * h, 2 * w), 402)
     gy = dg.hash_normalish((B, Cup + Cs, 2 * h, 2 * w), 403)
+    ssl = lazy_pair(Cup, 410) if lazy[0] else None
+    sss = lazy_pair(Cs, 420) if lazy[1] else None
     xd, sd = act(x, dtype).requires_grad_(True), act(skip, dtype).requires_grad_(True)
-    y = F_.UpsampleCatFn.apply(xd, sd)
+    y = F_.UpsampleCatFn.apply(xd, ssl.to(DEV) if lazy[0] else None, sd, sss.to(DEV) if lazy[1] else None)
     y.backward(act(gy, dtype))
-    xo, so = q(x, dtype).requires_grad_(True), q(skip, dtype).requires_grad_(True)
+    xo = (lazy_value(x, ssl, dtype) if lazy[0] else q(x, dtype)).requires_grad_(True)
+    so = (lazy_value(skip, sss, dtype) if lazy[1] else q(skip, dtype)).requires_grad_(True)
     yo = torch.cat([orc.upsample2x_bilinear(xo), so], dim=1)
     yo.backward(q(gy, dtype))
     assert rel_err(y, yo) < TOL[dtype] and rel_err(xd.grad, xo.grad) < TOL[dtype]
     assert torch.equal(sd.grad.float().cpu(), so.grad)
+    assert torch.equal(y[:, Cup:].float().cpu(), q(so.detach(), dtype))
 
 
 # ---------------------------------------------------------------------------
@@ -267,14 +298,15 @@ def _rnd(t, dtype):
     return t + (t.detach().to(dtype).to(t.dtype) - t.detach())
 
 
-def _cbr_oracle(x, w, b, gam, bet, gy, dtype):
+def _cbr_oracle(x, w, b, gam, bet, gy, dtype, x_value=None):
     """float64 oracle of one conv+BN(train)+ReLU with the inputs rounded to `dtype`.
     In bfloat16 mode it also rounds the tensors the kernels store in bfloat16 — the packed
     weights, the conv output z (statistics are taken before that rounding, from the float32
     accumulators), the activation a and the gradient dz — so the comparison isolates kernel
     errors from the storage format's own rounding."""
     # parameters stay float32 masters (only the packed conv weights are rounded, below)
-    xs = [q(x, dtype).double().requires_grad_(True)] + [T(v).double().requires_grad_(True) for v in (w, b, gam, bet)]
+    x0 = q(x, dtype) if x_value is None else q(x_value, dtype)
+    xs = [x0.double().requires_grad_(True)] + [T(v).double().requires_grad_(True) for v in (w, b, gam, bet)]
     xo, wo, bo, go, beo = xs
     if dtype == torch.float32:
         z = orc.conv3x3(xo, wo, bo)
@@ -298,9 +330,17 @@ CBR_SHAPES = [(2, 1, 8, 16, 16), (2, 3, 8, 16, 16), (2, 8, 32, 16, 16), (1, 32, 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", CBR_SHAPES)
-def test_conv_bn_relu(F_, dtype, shape):
+@pytest.mark.parametrize("lazy", [False, True])
+def test_conv_bn_relu(F_, dtype, shape, lazy):
+    """conv+BN(train)+ReLU returns the lazy pair (z, ss); materialised it is the activation.
+    With `lazy` the input itself is a lazy activation applied while the conv loads it."""
     B, Ci, Co, H, W = shape
     x = np.maximum(dg.hash_normalish((B, Ci, H, W), 501), 0) if Ci > 3 else dg.hash_normalish((B, Ci, H, W), 501)
+    ss_in = x_value = None
+    if lazy:
+        x = dg.hash_normalish((B, Ci, H, W), 501)
+        ss_in = lazy_pair(Ci, 510)
+        x_value = lazy_value(x, ss_in, dtype)
     w = dg.hash_normalish((Co, Ci, 3, 3), 502, std=(2.0 / (9 * Co)) ** 0.5)
     b = dg.hash_uniform((Co,), 503, -0.1, 0.1)
     gam = dg.hash_uniform((Co,), 504, 0.5, 1.5)
@@ -311,9 +351,11 @@ def test_conv_bn_relu(F_, dtype, shape):
     with torch.no_grad():
         conv.weight.copy_(T(w)); conv.bias.copy_(T(b)); bn.weight.copy_(T(gam)); bn.bias.copy_(T(bet))
     xd = act(x, dtype).requires_grad_(True)
-    a = F_.conv_bn_relu(xd, conv, bn, True)
+    z, ss = F_.conv_bn_relu(xd, ss_in.to(DEV) if lazy else None, conv, bn, True)
+    assert ss.shape == (2, Co) and not ss.requires_grad
+    a = F_.materialize(z, ss)
     a.backward(act(gy, dtype))
-    ao, grads, mean, var = _cbr_oracle(x, w, b, gam, bet, gy, dtype)
+    ao, grads, mean, var = _cbr_oracle(x, w, b, gam, bet, gy, dtype, x_value)
     tol = 2e-5 if dtype == torch.float32 else 1e-2
     gtol = 2e-4 if dtype == torch.float32 else 2e-2
     assert rel_err(a, ao) < tol
@@ -358,17 +400,19 @@ def test_double_conv_golden(F_, golden, name, c):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 32, 4, 16, 16), (1, 8, 9, 8, 24), (2, 16, 2, 8, 8)])
-def test_conv1x1(F_, dtype, shape):
+@pytest.mark.parametrize("lazy", [False, True])
+def test_conv1x1(F_, dtype, shape, lazy):
     B, Ci, Co, H, W = shape
     x = dg.hash_normalish((B, Ci, H, W), 601)
+    ss = lazy_pair(Ci, 610) if lazy else None
     w = dg.hash_normalish((Co, Ci, 1, 1), 602, std=0.3)
     b = dg.hash_uniform((Co,), 603, -0.1, 0.1)
     gy = dg.hash_normalish((B, Co, H, W), 604)
     wd, bd = T(w).to(DEV).requires_grad_(True), T(b).to(DEV).requires_grad_(True)
     xd = act(x, dtype).requires_grad_(True)
-    y = F_.Conv1x1Fn.apply(xd, wd, bd)
+    y = F_.Conv1x1Fn.apply(xd, ss.to(DEV) if lazy else None, wd, bd)
     y.backward(act(gy, dtype))
-    xo = q(x, dtype).double().requires_grad_(True)
+    xo = (lazy_value(x, ss, dtype) if lazy else q(x, dtype)).double().requires_grad_(True)
     wo, bo = T(w).double().requires_grad_(True), T(b).double().requires_grad_(True)
     yo = torch.nn.functional.conv2d(xo, wo, bo)
     yo.backward(q(gy, dtype).double())
@@ -391,7 +435,8 @@ MFMA_SHAPES = [  # B, Cin, Cout, H, W
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", MFMA_SHAPES)
 @pytest.mark.parametrize("transposed", [False, True])
-def test_conv3x3_mfma_vs_direct_and_oracle(F_, dtype, shape, transposed):
+@pytest.mark.parametrize("lazy", [False, True])
+def test_conv3x3_mfma_vs_direct_and_oracle(F_, dtype, shape, transposed, lazy):
     """z = conv(x, W) (+ statistics) for the forward operand and for the data-gradient
     operand (W^T, taps mirrored), on the matrix-core kernel and the vector-ALU kernel."""
     from medical_image_segmentation_amd import _lib
@@ -407,19 +452,23 @@ def test_conv3x3_mfma_vs_direct_and_oracle(F_, dtype, shape, transposed):
     xd = act(x, dtype)
     wd = T(wm).to(DEV)
     bd = None if transposed else T(b).to(DEV)
+    ss = lazy_pair(Ci, 710) if lazy else None
+    ssd = ss.to(DEV) if lazy else None
+    # the matrix-core kernel rounds the applied activation to the compute dtype (its operand type)
+    xv = q(lazy_value(x, ss, dtype), dtype) if lazy else q(x, dtype)
     outs = []
     for mode in (0, 1):
         _lib.call("mis_set_conv_path", mode)
         try:
             wp = F_.pack_weights(wd, dtype, transposed=transposed)
-            z, stats = F_.conv3x3_raw(xd, wp, bd, Co, True)
+            z, stats = F_.conv3x3_raw(xd, wp, bd, Co, True, ssd)
             torch.cuda.synchronize()
         finally:
             _lib.call("mis_set_conv_path", 0)
         outs.append((z.float().cpu(), stats.cpu()))
     wq = q(wm, dtype).double()
     w_eff = wq.flip(2, 3).transpose(0, 1) if transposed else wq
-    zo = torch.nn.functional.conv2d(q(x, dtype).double(), w_eff, None if transposed else T(b).double(), padding=1)
+    zo = torch.nn.functional.conv2d(xv.double(), w_eff, None if transposed else T(b).double(), padding=1)
     tol = 1e-5 if dtype == torch.float32 else 1e-2
     for z, stats in outs:
         assert rel_err(z, zo) < tol
@@ -437,24 +486,35 @@ WGRAD_SHAPES = [  # B, Cin, Cout, H, W
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", WGRAD_SHAPES)
-def test_conv3x3_wgrad_mfma_vs_direct_and_oracle(F_, dtype, shape):
+@pytest.mark.parametrize("lazy", [False, True])
+def test_conv3x3_wgrad_mfma_vs_direct_and_oracle(F_, dtype, shape, lazy):
     from medical_image_segmentation_amd import _lib
     B, Ci, Co, H, W = shape
     x = np.maximum(dg.hash_normalish((B, Ci, H, W), 801), 0)
     gz = dg.hash_normalish((B, Co, H, W), 802)
+    ssd = None
+    xv = q(x, dtype)
+    if lazy:
+        x = dg.hash_normalish((B, Ci, H, W), 801)
+        ss = lazy_pair(Ci, 810)
+        ssd = ss.to(DEV)
+        xv = lazy_value(x, ss, dtype)
     xd, gd = act(x, dtype), act(gz, dtype)
     outs = []
     for mode in (0, 1):
         _lib.call("mis_set_conv_path", mode)
         try:
-            outs.append(F_.conv3x3_wgrad_raw(xd, gd).cpu())
+            outs.append(F_.conv3x3_wgrad_raw(xd, gd, ssd).cpu())
             torch.cuda.synchronize()
         finally:
             _lib.call("mis_set_conv_path", 0)
-    xo = q(x, dtype).double()
+    xo = xv.double()
     wo = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv2d(xo, wo, None, padding=1).backward(q(gz, dtype).double())
+    # plain inputs are exact in both dtypes (float32 accumulation); a lazy bf16 input is rounded
+    # to bf16 after the affine by the matrix-core kernel
+    tol = 2e-5 if not (lazy and dtype == torch.bfloat16) else 3e-3
     for dw in outs:
         assert dw.shape == (Co, Ci, 3, 3)
-        assert rel_err(dw, wo.grad) < 2e-5      # inputs are exact in both dtypes; float32 accumulation
-    assert rel_err(outs[0], outs[1]) < 2e-5
+        assert rel_err(dw, wo.grad) < tol
+    assert rel_err(outs[0], outs[1]) < tol

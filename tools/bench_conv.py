@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--lazy", action="store_true", help="input is a lazy activation (affine+ReLU applied on load)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     es = 2 if dt == torch.bfloat16 else 4
@@ -56,9 +57,10 @@ def main():
         by = n * (ci + co) * es
         fl = 18 * n * ci * co
         t_ideal = max(by / 6.3e12, fl / 2.5e15) * 1e6
-        tf = timeit(lambda: F_.conv3x3_raw(x, wf, b, co, True), args.iters)
+        ss = torch.rand(2, ci, device=dev) if args.lazy else None
+        tf = timeit(lambda: F_.conv3x3_raw(x, wf, b, co, True, ss), args.iters)
         td = timeit(lambda: F_.conv3x3_raw(dz, wd, None, ci, False), args.iters) if ci >= 8 else float("nan")
-        tw = timeit(lambda: F_.conv3x3_wgrad_raw(x, dz), args.iters)
+        tw = timeit(lambda: F_.conv3x3_wgrad_raw(x, dz, ss), args.iters)
         f = lambda t: (by / t / 1e6, fl / t / 1e6)
         print(f"{name:8s} {ci:4d}->{co:4d} @{hw:4d} | {tf:8.1f} {f(tf)[0]:5.2f} {f(tf)[1]:6.1f} {t_ideal:6.1f} | "
               f"{td:8.1f} {f(td)[0]:5.2f} {f(td)[1]:6.1f} | {tw:8.1f} {f(tw)[0]:5.2f} {f(tw)[1]:6.1f}")
