@@ -98,9 +98,12 @@ int mis_loss_bwd(const void* logits, int dtype, int64_t stride_b, int64_t stride
 int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, int H, int W, int C, void* y,
                        mis_stream_t stream);
 /* dx = gradient routed to the first maximum of each window (row-major scan,    */
-/* strict '>'), zero elsewhere; x is the forward input.                         */
-int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int B, int H, int W, int C,
-                       void* dx, mis_stream_t stream);
+/* strict '>'), zero elsewhere; x is the forward input.  dx_add (nullable, may    */
+/* alias dx) is a second gradient of x — the encoder output also feeds the       */
+/* decoder as a skip connection (model/unet.py:67,72,77,81) — summed in here      */
+/* (autograd's accumulation of the two uses, without a separate pass).           */
+int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, const void* dx_add, int dtype, int B,
+                       int H, int W, int C, void* dx, mis_stream_t stream);
 /* out[b][2h][2w][0:Cup] = bilinear(low), out[...][Cup:Cup+Cskip] = skip.        */
 int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const void* skip, const float* skip_affine,
                            int dtype, int B, int h, int w, int Cup, int Cskip, void* out, mis_stream_t stream);

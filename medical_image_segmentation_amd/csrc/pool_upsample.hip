@@ -59,7 +59,7 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __rest
 
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                                 T* __restrict__ dx, int B, int H, int W, int C,
+                                                                 const T* add, T* dx, int B, int H, int W, int C,
                                                                  const float* __restrict__ in_aff) {
   extern __shared__ float aff_lds[];
   const float* aff = nullptr;
@@ -99,6 +99,20 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __rest
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) o[j][k] = (am == j) ? g[k] : 0.f;
+    }
+    if (add) {
+      // a second gradient of the same tensor (its use as a skip connection), summed here instead
+      // of in a separate pass; `add` may alias dx (each lane reads exactly what it overwrites)
+      const T* asrc = add + off;
+      float a4[4][V];
+      vload<T, V>(asrc, a4[0]);
+      vload<T, V>(asrc + C, a4[1]);
+      vload<T, V>(asrc + (int64_t)W * C, a4[2]);
+      vload<T, V>(asrc + (int64_t)W * C + C, a4[3]);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < V; k++) o[j][k] += a4[j][k];
     }
     T* dst = dx + off;
     vstore<T, V>(dst, o[0]);
@@ -259,16 +273,17 @@ int pool_fwd(const void* x, void* y, int B, int H, int W, int C, const float* af
 }
 
 template <typename T>
-int pool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, const float* aff, hipStream_t st) {
+int pool_bwd(const void* x, const void* dy, const void* add, void* dx, int B, int H, int W, int C, const float* aff,
+             hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
   const size_t lds = aff ? 2 * (size_t)C * sizeof(float) : 0;
-  if (pick_vec<T>(C, x, dy, dx) == N)
-    maxpool_bwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (T*)dx,
-                                                                                    B, H, W, C, aff);
+  if (pick_vec<T>(C, x, dy, dx, add) == N)
+    maxpool_bwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>(
+        (const T*)x, (const T*)dy, (const T*)add, (T*)dx, B, H, W, C, aff);
   else
-    maxpool_bwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (T*)dx, B, H,
-                                                                                W, C, aff);
+    maxpool_bwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>(
+        (const T*)x, (const T*)dy, (const T*)add, (T*)dx, B, H, W, C, aff);
   return 0;
 }
 
@@ -331,14 +346,14 @@ int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, i
   return MIS_OK;
 }
 
-int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int B, int H, int W, int C,
-                       void* dx, mis_stream_t stream) {
+int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, const void* dx_add, int dtype, int B,
+                       int H, int W, int C, void* dx, mis_stream_t stream) {
   MIS_REQUIRE(x && dy && dx, "maxpool2x2_bwd: null pointer");
   MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
               "maxpool2x2_bwd: H and W must be even and >= 2 (got %dx%d)", H, W);
   MIS_REQUIRE(C <= 4096, "maxpool2x2_bwd: C too large");
-  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx, B, H, W, C, x_affine, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx, B, H, W, C, x_affine, (hipStream_t)stream);
+  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx_add, dx, B, H, W, C, x_affine, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx_add, dx, B, H, W, C, x_affine, (hipStream_t)stream);
   else MIS_REQUIRE(false, "maxpool2x2_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("maxpool_bwd_kernel");
   return MIS_OK;

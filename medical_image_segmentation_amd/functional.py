@@ -274,29 +274,64 @@ def conv_bn_relu(x, x_ss, conv, bn, training):
 # ---------------------------------------------------------------------------
 # Down / Up   (model/unet.py:19-20, 48-81)
 # ---------------------------------------------------------------------------
+def _maxpool_fwd(x, x_ss):
+    _check_act(x)
+    B, Cc, H, W = x.shape
+    if H % 2 or W % 2:
+        raise ValueError(f"max-pool 2x2 needs even H and W, got {H}x{W}")
+    y = _empty_act(B, Cc, H // 2, W // 2, x)
+    with _prof("maxpool2x2_fwd", 0, (x.numel() + y.numel()) * x.element_size()):
+        call("mis_maxpool2x2_fwd", x.data_ptr(), _p(x_ss), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
+    return y
+
+
+def _maxpool_bwd(x, x_ss, dy, dx_add=None):
+    """Gradient of the pooled activation routed to each window's first maximum, plus `dx_add`
+    (a second gradient of the same tensor); autograd's gradient buffers are never written."""
+    B, Cc, H, W = x.shape
+    dy = to_act(dy, x.dtype)
+    if dx_add is not None:
+        dx_add = to_act(dx_add, x.dtype)
+    dx = torch.empty_like(x)
+    nbytes = (2 * x.numel() + dy.numel() + (x.numel() if dx_add is not None else 0)) * x.element_size()
+    with _prof("maxpool2x2_bwd", 0, nbytes):
+        call("mis_maxpool2x2_bwd", x.data_ptr(), _p(x_ss), dy.data_ptr(), _p(dx_add), _dt(x), B, H, W, Cc,
+             dx.data_ptr(), _stream())
+    return dx
+
+
 class MaxPool2x2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x_ss):
-        _check_act(x)
-        B, Cc, H, W = x.shape
-        if H % 2 or W % 2:
-            raise ValueError(f"max-pool 2x2 needs even H and W, got {H}x{W}")
-        y = _empty_act(B, Cc, H // 2, W // 2, x)
-        with _prof("maxpool2x2_fwd", 0, (x.numel() + y.numel()) * x.element_size()):
-            call("mis_maxpool2x2_fwd", x.data_ptr(), _p(x_ss), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
+        y = _maxpool_fwd(x, x_ss)
         ctx.save_for_backward(x, x_ss)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, x_ss = ctx.saved_tensors
-        B, Cc, H, W = x.shape
-        dy = to_act(dy, x.dtype)
-        dx = torch.empty_like(x)
-        with _prof("maxpool2x2_bwd", 0, (2 * x.numel() + dy.numel()) * x.element_size()):
-            call("mis_maxpool2x2_bwd", x.data_ptr(), _p(x_ss), dy.data_ptr(), _dt(x), B, H, W, Cc, dx.data_ptr(),
-                 _stream())
-        return dx, None
+        return _maxpool_bwd(x, x_ss, dy), None
+
+
+class PoolSkipFn(torch.autograd.Function):
+    """An encoder output used twice: max-pooled for the next level, and (as the very same
+    tensor) as the decoder's skip connection — unet.py:47-60,67-81.  (x, x_ss) -> (pooled, skip)
+    with skip an alias of x; the backward receives both gradients at once and sums them inside
+    the pooling backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, x_ss):
+        y = _maxpool_fwd(x, x_ss)
+        ctx.save_for_backward(x, x_ss)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, x_ss = ctx.saved_tensors
+        if dy is None:
+            return dskip, None
+        return _maxpool_bwd(x, x_ss, dy, dskip), None
 
 
 class UpsampleCatFn(torch.autograd.Function):

@@ -61,16 +61,21 @@ class UNet(nn.Module):
             raise ValueError(f"expected [B, {self.in_channels}, H, W], got {tuple(x.shape)}")
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
-        down, upcat = F_.MaxPool2x2Fn.apply, F_.UpsampleCatFn.apply
+        down, upcat = F_.PoolSkipFn.apply, F_.UpsampleCatFn.apply
         drop = self._drop
         x = F_.to_act(x, self._dtype())
         # every DoubleConv output stays lazy (z, ss): pool, upsample+concat, the next conv and the
-        # 1x1 head apply its BatchNorm affine + ReLU while loading it
+        # 1x1 head apply its BatchNorm affine + ReLU while loading it.  `down` returns the pooled
+        # tensor and the skip alias of its input, so both gradients meet in one kernel.
         z1, s1 = self.encoder1.forward_lazy(x)
-        z2, s2 = self.encoder2.forward_lazy(drop(self.encoder_dropout1, down(z1, s1)))
-        z3, s3 = self.encoder3.forward_lazy(drop(self.encoder_dropout2, down(z2, s2)))
-        z4, s4 = self.encoder4.forward_lazy(drop(self.encoder_dropout3, down(z3, s3)))
-        x5 = drop(self.encoder_dropout4, down(z4, s4))
+        p1, z1 = down(z1, s1)
+        z2, s2 = self.encoder2.forward_lazy(drop(self.encoder_dropout1, p1))
+        p2, z2 = down(z2, s2)
+        z3, s3 = self.encoder3.forward_lazy(drop(self.encoder_dropout2, p2))
+        p3, z3 = down(z3, s3)
+        z4, s4 = self.encoder4.forward_lazy(drop(self.encoder_dropout3, p3))
+        p4, z4 = down(z4, s4)
+        x5 = drop(self.encoder_dropout4, p4)
         y, sy = self._lazy_drop(self.bottleneck_dropout, *self.center_conv.forward_lazy(x5))
         y, sy = self._lazy_drop(self.decoder_dropout1, *self.decoder1.forward_lazy(upcat(y, sy, z4, s4)))
         y, sy = self._lazy_drop(self.decoder_dropout2, *self.decoder2.forward_lazy(upcat(y, sy, z3, s3)))

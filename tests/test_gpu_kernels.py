@@ -230,6 +230,18 @@ def test_maxpool_random(F_, dtype, shape, lazy):
     yo.backward(q(gy, dtype))
     assert torch.equal(y.float().cpu(), q(yo.detach(), dtype))
     assert torch.equal(xd.grad.float().cpu(), xo.grad)
+    # pooled + skip use of the same tensor: both gradients are summed inside the pooling backward
+    gs = dg.hash_normalish(shape, 303)
+    xd2 = act(x, dtype).requires_grad_(True)
+    y2, skip = F_.PoolSkipFn.apply(xd2, ssd)
+    assert skip.data_ptr() == xd2.data_ptr() and torch.equal(y2, y)
+    torch.autograd.backward([y2, skip], [act(gy, dtype), act(gs, dtype)])
+    want = q(xo.grad + q(gs, dtype), dtype)
+    assert torch.equal(xd2.grad.float().cpu(), want)
+    xd3 = act(x, dtype).requires_grad_(True)      # only the skip branch carries a gradient
+    _, skip3 = F_.PoolSkipFn.apply(xd3, ssd)
+    skip3.backward(act(gs, dtype))
+    assert torch.equal(xd3.grad.float().cpu(), q(gs, dtype))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
