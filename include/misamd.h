@@ -147,6 +147,30 @@ size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout)
 int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W,
                       int Cin, int Cout, float* dw, void* workspace, mis_stream_t stream);
 
+/* The decoder's `torch.cat([up(x), skip], dim=1)` followed by a 3x3 conv         */
+/* (model/unet.py:66-68, 71-73, 76-78, 80-82) without materialising the          */
+/* concatenation: the conv reads its input channels [0,Ca) from xa and [Ca,Ca+Cb) */
+/* from xb (two dense channels-last tensors, each with its own optional lazy      */
+/* affine), the weight gradient does the same, and the data gradient is written   */
+/* as two tensors (the gradient of `up` and the gradient of the skip connection). */
+/* w_packed is the ordinary packed image of the [Cout][Ca+Cb][3][3] weights        */
+/* (transposed=0 for cat_fwd; transposed=1, producing Ca+Cb channels, for          */
+/* split_fwd).  mis_conv3x3_cat_supported returns 1 when all three take the shape */
+/* (matrix-core kernels only: equal Ca == Cb that are whole 32-channel (bf16) /    */
+/* 16-channel (f32) chunks); otherwise concatenate and use the one-tensor calls.  */
+/* Workspaces: mis_conv3x3_workspace_bytes / mis_conv3x3_wgrad_workspace_bytes     */
+/* with Cin = Ca+Cb.                                                               */
+int mis_conv3x3_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout);
+int mis_conv3x3_cat_fwd(const void* xa, const float* xa_affine, const void* xb, const float* xb_affine,
+                        const void* w_packed, const float* bias, int dtype, int B, int H, int W,
+                        int Ca, int Cb, int Cout, void* z, float* stats, void* workspace, mis_stream_t stream);
+int mis_conv3x3_split_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype,
+                          int B, int H, int W, int Cin, int Ca, int Cb, void* za, void* zb, void* workspace,
+                          mis_stream_t stream);
+int mis_conv3x3_cat_wgrad(const void* xa, const float* xa_affine, const void* xb, const float* xb_affine,
+                          const void* dz, int dtype, int B, int H, int W, int Ca, int Cb, int Cout,
+                          float* dw, void* workspace, mis_stream_t stream);
+
 /* Training-mode BatchNorm2d statistics -> per-channel affine + running stats.   */
 /* stats float32 [2][C] (sum, sum of squares over n = B*H*W values per channel). */
 /* scale_shift float32 [2][C]: y = z*scale + shift with                          */

@@ -64,8 +64,8 @@ int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, 
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_fwd: bad dtype %d", dtype);
   MIS_REQUIRE((int64_t)B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < ((int64_t)1 << 40), "conv3x3_fwd: tensor too large");
   if (use_mfma(dtype, Cin, Cout))
-    return conv3x3_mfma_fwd(x, x_affine, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace,
-                            (hipStream_t)stream);
+    return conv3x3_mfma_fwd(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, w_packed, bias, dtype, B, H, W,
+                            ConvOut{z, Cout, nullptr, 0}, stats, workspace, (hipStream_t)stream);
   return conv3x3_direct_fwd(x, x_affine, w_packed, bias, dtype, B, H, W, Cin, Cout, z, stats, workspace,
                             (hipStream_t)stream);
 }
@@ -83,8 +83,60 @@ int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int 
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_wgrad: bad shape");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_wgrad: bad dtype %d", dtype);
   if (!force_direct() && workspace && conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout))
-    return conv3x3_wgrad_mfma(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, workspace, (hipStream_t)stream);
+    return conv3x3_wgrad_mfma(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, dz, dtype, B, H, W, Cout, dw, workspace,
+                              (hipStream_t)stream);
   return conv3x3_direct_wgrad(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, (hipStream_t)stream);
+}
+
+int mis_conv3x3_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Ca < 1 || Cb < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
+  if (force_direct()) return 0;
+  return (conv3x3_mfma_cat_supported(dtype, Ca, Cb, Cout) &&            // forward: two-tensor input
+          conv3x3_mfma_split_supported(dtype, Cout, Ca, Cb) &&          // data gradient: two-tensor output
+          conv3x3_wgrad_mfma_cat_supported(dtype, B, H, W, Ca, Cb, Cout)) ? 1 : 0;
+}
+
+int mis_conv3x3_cat_fwd(const void* xa, const float* xa_affine, const void* xb, const float* xb_affine,
+                        const void* w_packed, const float* bias, int dtype, int B, int H, int W, int Ca, int Cb,
+                        int Cout, void* z, float* stats, void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(xa && xb && w_packed && z, "conv3x3_cat_fwd: null pointer");
+  MIS_REQUIRE(!stats || workspace, "conv3x3_cat_fwd: stats requested without a workspace");
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Ca >= 1 && Cb >= 1 && Cout >= 1, "conv3x3_cat_fwd: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_cat_fwd: bad dtype %d", dtype);
+  if (force_direct() || !conv3x3_mfma_cat_supported(dtype, Ca, Cb, Cout)) {
+    mis_set_error("conv3x3_cat_fwd: unsupported channel split %d+%d -> %d (concatenate and use conv3x3_fwd)", Ca, Cb, Cout);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  return conv3x3_mfma_fwd(ConvIn{xa, xa_affine, Ca, xb, xb_affine, Cb}, w_packed, bias, dtype, B, H, W,
+                          ConvOut{z, Cout, nullptr, 0}, stats, workspace, (hipStream_t)stream);
+}
+
+int mis_conv3x3_split_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype,
+                          int B, int H, int W, int Cin, int Ca, int Cb, void* za, void* zb, void* workspace,
+                          mis_stream_t stream) {
+  MIS_REQUIRE(x && w_packed && za && zb, "conv3x3_split_fwd: null pointer");
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Ca >= 1 && Cb >= 1, "conv3x3_split_fwd: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_split_fwd: bad dtype %d", dtype);
+  if (force_direct() || !conv3x3_mfma_split_supported(dtype, Cin, Ca, Cb)) {
+    mis_set_error("conv3x3_split_fwd: unsupported channel split %d -> %d+%d", Cin, Ca, Cb);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  return conv3x3_mfma_fwd(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, w_packed, bias, dtype, B, H, W,
+                          ConvOut{za, Ca, zb, Cb}, nullptr, workspace, (hipStream_t)stream);
+}
+
+int mis_conv3x3_cat_wgrad(const void* xa, const float* xa_affine, const void* xb, const float* xb_affine,
+                          const void* dz, int dtype, int B, int H, int W, int Ca, int Cb, int Cout, float* dw,
+                          void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(xa && xb && dz && dw && workspace, "conv3x3_cat_wgrad: null pointer");
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Ca >= 1 && Cb >= 1 && Cout >= 1, "conv3x3_cat_wgrad: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_cat_wgrad: bad dtype %d", dtype);
+  if (force_direct() || !conv3x3_wgrad_mfma_cat_supported(dtype, B, H, W, Ca, Cb, Cout)) {
+    mis_set_error("conv3x3_cat_wgrad: unsupported channel split %d+%d -> %d", Ca, Cb, Cout);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  return conv3x3_wgrad_mfma(ConvIn{xa, xa_affine, Ca, xb, xb_affine, Cb}, dz, dtype, B, H, W, Cout, dw, workspace,
+                            (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -13,14 +13,33 @@ int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int 
 size_t conv3x3_direct_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_direct_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
 
+// Input of a conv: one tensor (xb == nullptr, Cb == 0), or the channel concatenation [xa | xb]
+// of two that is never materialised.  Each tensor is dense channels-last with its own channel
+// count and its own optional lazy-activation affine ([2][C]).
+struct ConvIn {
+  const void* xa; const float* affa; int Ca;
+  const void* xb; const float* affb; int Cb;
+  int channels() const { return Ca + Cb; }
+};
+// Output of a conv: one tensor (zb == nullptr, Cb == 0), or split by channel into two dense
+// tensors: channels [0, Ca) -> za, [Ca, Ca+Cb) -> zb.
+struct ConvOut {
+  void* za; int Ca;
+  void* zb; int Cb;
+  int channels() const { return Ca + Cb; }
+};
+
 // Matrix-core path (conv_mfma.hip).  *_supported tell whether the shape is taken.
 bool conv3x3_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
+bool conv3x3_mfma_cat_supported(int dtype, int Ca, int Cb, int Cout);          // two-tensor input
+bool conv3x3_mfma_split_supported(int dtype, int Cin, int Ca, int Cb);         // two-tensor output
 size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
-int conv3x3_mfma_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
-                     int W, int Cin, int Cout, void* z, float* stats, void* workspace, hipStream_t st);
+int conv3x3_mfma_fwd(const ConvIn& in, const void* wp, const float* bias, int dtype, int B, int H, int W,
+                     const ConvOut& out, float* stats, void* workspace, hipStream_t st);
 size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
 bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
 size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
-int conv3x3_wgrad_mfma(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
-                       int Cout, float* dw, void* workspace, hipStream_t st);
+bool conv3x3_wgrad_mfma_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout);
+int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, float* dw,
+                       void* workspace, hipStream_t st);

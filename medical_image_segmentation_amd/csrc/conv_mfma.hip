@@ -138,9 +138,14 @@ constexpr int fwd_min_blocks(int nt, int cpg) { return (nt == 4 || nt * cpg >= 6
 
 template <typename T, int NT, int CPG>
 __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_mfma_kernel(
-    const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias, T* __restrict__ z,
-    float* __restrict__ partials, int B, int H, int W, int Cin, int Cout, int n_chunks, int nt_total, int tiles_x,
-    int tiles_y, int n_tiles, const float* __restrict__ in_aff) {
+    const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ wp, const float* __restrict__ bias,
+    T* __restrict__ za, T* __restrict__ zb, float* __restrict__ partials, int B, int H, int W, int Cin, int Cs,
+    int n_chunks_a, int Cout, int Cout_a, int n_chunks, int nt_total, int tiles_x, int tiles_y, int n_tiles,
+    const float* __restrict__ affa, const float* __restrict__ affb) {
+  // Input channels [0, Cs) come from xa and — two-tensor input — [Cs, Cin) from xb (same
+  // channel count, chunks n_chunks_a.. of the K loop); both tensors have pixel stride Cs.
+  // Output channels [0, Cout_a) go to za and — two-tensor output — [Cout_a, Cout) to zb; a
+  // workgroup's channel slice lies in one of them (the host picks NT accordingly).
   constexpr int G = Mf<T>::G;
   using Frag = typename Mf<T>::Frag;
   constexpr int NS = nsteps_of(CPG);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   int tid_l = tid;        // laundered per stage when !PRE, so the recomputation is not hoisted (and spilled)
   auto halo_rel = [&](int i) -> unsigned {      // byte offset of element i relative to the halo origin
     const int v = tid_l + i * CM_THREADS, pos = v / CPG, cg = v % CPG;
-    return (unsigned)((((pos / HW_) * W + pos % HW_) * Cin + cg * G) * (int)sizeof(T));
+    return (unsigned)((((pos / HW_) * W + pos % HW_) * Cs + cg * G) * (int)sizeof(T));
   };
   auto halo_px = [&](int i) -> int {            // its halo column (huge for tail elements: never loaded)
     const int v = tid_l + i * CM_THREADS;
@@ -212,15 +217,19 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     }
   }
   // lane offsets of the epilogue stores inside the tile (bytes), OOB for padded channels
+  const bool zsel = zb != nullptr && n0 * 16 >= Cout_a;          // this workgroup writes the second tensor
+  T* const zs = zsel ? zb : za;
+  const int Cz = zb == nullptr ? Cout : (zsel ? Cout - Cout_a : Cout_a);   // its channel count
   unsigned z_rel[NSTORE];
 #pragma unroll
   for (int j = 0; j < NSTORE; j++) {
     int co;
     if constexpr (PAIR) co = (n0 + 2 * j) * 16 + ((kg & 1) ? 16 + 4 * (kg - 1) : 4 * kg);
     else co = (n0 + j) * 16 + 4 * kg;
-    z_rel[j] = (co < Cout) ? (unsigned)((((wid * MT) * W + col) * Cout + co) * (int)sizeof(T)) : OOB;
+    const int cl = co - (zsel ? Cout_a : 0);
+    z_rel[j] = (co < Cout) ? (unsigned)((((wid * MT) * W + col) * Cz + cl) * (int)sizeof(T)) : OOB;
   }
-  const unsigned z_row = (unsigned)(W * Cout * (int)sizeof(T));
+  const unsigned z_row = (unsigned)(W * Cz * (int)sizeof(T));
 
   f32x4 s1[NT], s2[NT];
 #pragma unroll
@@ -235,14 +244,17 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   // (negative or too-large offsets); only the column needs a compare.  This implements the
   // conv's zero padding without a branch or a select on the loaded value, so the loads stay in
   // flight under the MFMAs.  A dead stage (past the last tile) shifts x far left: nothing loads.
-  const int img_bytes = H * W * Cin * (int)sizeof(T);
+  const int img_bytes = H * W * Cs * (int)sizeof(T);
 #define LOAD_HALO(P, CHUNK, LIVE)                                                                        \
   {                                                                                                      \
     const int xo_ = (P).tx * TW - 1, yo_ = (P).ty * TH - 1;                                              \
     const int x0_ = ((LIVE) && !(MIS_DBG & 4)) ? xo_ : -(1 << 29);                                       \
-    const unsigned base_ = (unsigned)(((yo_ * W + xo_) * Cin + (CHUNK) * KC) * (int)sizeof(T));          \
+    const bool sb_ = (CHUNK) >= n_chunks_a;                                                              \
+    const T* xs_ = sb_ ? xb : xa;                                                                        \
+    const int cc_ = sb_ ? (CHUNK) - n_chunks_a : (CHUNK);                                                \
+    const unsigned base_ = (unsigned)(((yo_ * W + xo_) * Cs + cc_ * KC) * (int)sizeof(T));               \
     const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                \
-        (void*)(x + (int64_t)(P).b * H * W * Cin), 0, img_bytes, 0x00020000);                            \
+        (void*)(xs_ + (int64_t)(P).b * H * W * Cs), 0, img_bytes, 0x00020000);                           \
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
       const bool ok = (unsigned)(x0_ + (PRE ? h_px[PRE ? i : 0] : halo_px(i))) < (unsigned)W;            \
       const unsigned rel_ = PRE ? h_rel[PRE ? i : 0] : halo_rel(i);                                      \
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   {                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
       u32x4 val = hreg[i];                                                                               \
-      if (in_aff) {                                                                                      \
+      if (((CHUNK) >= n_chunks_a) ? (affb != nullptr) : (affa != nullptr)) {                             \
         const int v = tid + i * CM_THREADS;                                                              \
         const int pos = v / CPG, cg = v % CPG;                                                           \
         const int gy = (P).ty * TH - 1 + pos / HW_, gx = (P).tx * TW - 1 + pos % HW_;                    \
@@ -309,8 +321,8 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
       }                                                                                                  \
     }                                                                                                    \
     const __amdgpu_buffer_rsrc_t zrs_ = __builtin_amdgcn_make_buffer_rsrc(                               \
-        (void*)(z + (int64_t)cur.b * H * W * Cout), 0, H * W * Cout * (int)sizeof(T), 0x00020000);       \
-    const unsigned zb_ = (unsigned)(((cur.ty * TH * W) + cur.tx * TW) * Cout * (int)sizeof(T));          \
+        (void*)(zs + (int64_t)cur.b * H * W * Cz), 0, H * W * Cz * (int)sizeof(T), 0x00020000);          \
+    const unsigned zb_ = (unsigned)(((cur.ty * TH * W) + cur.tx * TW) * Cz * (int)sizeof(T));            \
     _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                     \
       const unsigned zm_ = zb_ + (unsigned)m * z_row;                                                    \
       _Pragma("unroll") for (int j = 0; j < NSTORE; j++) {                                               \
@@ -341,8 +353,13 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     const int co = n0 * 16 + i;
     biasl[i] = (bias && co < Cout) ? bias[co] : 0.f;
   }
-  if (in_aff) {
-    for (int i = tid; i < 2 * Cin; i += CM_THREADS) aff[i] = in_aff[i];     // visible after the first barrier below
+  // combined affine table [2][Cin] of the (up to two) lazy inputs; visible after the first barrier below
+  if (affa) {
+    for (int i = tid; i < 2 * Cs; i += CM_THREADS) aff[(i / Cs) * Cin + i % Cs] = affa[i];
+  }
+  if (affb) {
+    const int Cb = Cin - Cs;
+    for (int i = tid; i < 2 * Cb; i += CM_THREADS) aff[(i / Cb) * Cin + Cs + i % Cb] = affb[i];
   }
   // this workgroup's contiguous tile range
   const int nb_ = gridDim.x, q_ = n_tiles / nb_, r_ = n_tiles % nb_;
@@ -493,8 +510,10 @@ struct FwdPlan {
   size_t lds;
 };
 
+// Ca_in: channels of the first input tensor (== Cin for one tensor); Cout_a: channels of the
+// first output tensor (== Cout for one tensor).
 template <typename T>
-bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
+bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1, int Cout_a = -1) {
   constexpr int G = Mf<T>::G;
   if (Cin % G != 0 || Cout % 4 != 0 || Cin < G) return false;
   const int groups = Cin / G;
@@ -507,10 +526,20 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
   } else {
     return false;
   }
+  if (Ca_in >= 0 && Ca_in != Cin) {
+    // two input tensors: equal channel counts, each a whole number of K chunks
+    if (p.CPG != 4 || 2 * Ca_in != Cin || Ca_in % (4 * G) != 0) return false;
+  }
   p.nt_total = (Cout + 15) / 16;
   p.NT = p.nt_total >= 4 ? 4 : (p.nt_total >= 2 ? 2 : 1);
   if (p.nt_total % p.NT != 0) p.NT = (p.nt_total % 2 == 0) ? 2 : 1;
   if (sizeof(T) == 2 && Cout % 8 != 0) p.NT = 1;      // the paired 16-byte stores need whole 8-channel groups
+  if (Cout_a >= 0 && Cout_a != Cout) {
+    // two output tensors: a workgroup's 16*NT channel slice must lie inside one of them
+    if (Cout_a % 16 != 0 || Cout_a <= 0 || Cout_a >= Cout) return false;
+    while ((Cout_a / 16) % p.NT != 0) p.NT /= 2;
+    if (sizeof(T) == 2 && (Cout - Cout_a) % 8 != 0) p.NT = 1;
+  }
   p.grid_y = p.nt_total / p.NT;
   const int TH = 4 * fwd_mt(p.NT, p.CPG);
   p.tiles_x = (W + TW - 1) / TW;
@@ -531,45 +560,56 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p) {
   return true;
 }
 
+struct FwdArgs {
+  ConvIn in;
+  ConvOut out;
+  const void* wp;
+  const float* bias;
+  float* partials;
+  int B, H, W;
+};
+
 template <typename T, int NT, int CPG>
-void launch_fwd_k(const FwdPlan& p, const void* x, const float* in_aff, const void* wp, const float* bias, void* z,
-                  float* partials, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+void launch_fwd_k(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
   auto kfn = conv3x3_mfma_kernel<T, NT, CPG>;
   if (p.lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+  const int Cin = a.in.channels(), Cout = a.out.channels();
+  const int n_chunks_a = a.in.xb ? a.in.Ca / (4 * Mf<T>::G) : p.n_chunks;
   kfn<<<dim3(p.grid_x, p.grid_y), CM_THREADS, p.lds, st>>>(
-      (const T*)x, (const T*)wp, bias, (T*)z, partials, B, H, W, Cin, Cout, p.n_chunks, p.nt_total, p.tiles_x,
-      p.tiles_y, p.n_tiles, in_aff);
+      (const T*)a.in.xa, (const T*)a.in.xb, (const T*)a.wp, a.bias, (T*)a.out.za, (T*)a.out.zb, a.partials, a.B, a.H,
+      a.W, Cin, a.in.Ca, n_chunks_a, Cout, a.out.Ca, p.n_chunks, p.nt_total, p.tiles_x, p.tiles_y, p.n_tiles,
+      a.in.affa, a.in.affb);
 }
 
 template <typename T, int NT>
-void launch_fwd_cpg(const FwdPlan& p, const void* x, const float* in_aff, const void* wp, const float* bias, void* z,
-                    float* partials, int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+void launch_fwd_cpg(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
   switch (p.CPG) {
-    case 1: launch_fwd_k<T, NT, 1>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    case 2: launch_fwd_k<T, NT, 2>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    case 3: launch_fwd_k<T, NT, 3>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    default: launch_fwd_k<T, NT, 4>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 1: launch_fwd_k<T, NT, 1>(p, a, st); break;
+    case 2: launch_fwd_k<T, NT, 2>(p, a, st); break;
+    case 3: launch_fwd_k<T, NT, 3>(p, a, st); break;
+    default: launch_fwd_k<T, NT, 4>(p, a, st); break;
   }
 }
 
 template <typename T>
-int run_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int B, int H, int W, int Cin, int Cout,
-            void* z, float* stats, void* workspace, hipStream_t st) {
+int run_fwd(const ConvIn& in, const void* wp, const float* bias, int B, int H, int W, const ConvOut& out,
+            float* stats, void* workspace, hipStream_t st) {
   FwdPlan p;
-  if (!plan_fwd<T>(B, H, W, Cin, Cout, p)) {
-    mis_set_error("conv3x3_mfma: unsupported shape Cin=%d Cout=%d", Cin, Cout);
+  const int Cin = in.channels(), Cout = out.channels();
+  if (!plan_fwd<T>(B, H, W, Cin, Cout, p, in.Ca, out.Ca)) {
+    mis_set_error("conv3x3_mfma: unsupported shape Cin=%d+%d Cout=%d+%d", in.Ca, in.Cb, out.Ca, out.Cb);
     return MIS_ERR_UNSUPPORTED;
   }
-  float* partials = stats ? (float*)workspace : nullptr;
+  FwdArgs a{in, out, wp, bias, stats ? (float*)workspace : nullptr, B, H, W};
   switch (p.NT) {
-    case 1: launch_fwd_cpg<T, 1>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    case 2: launch_fwd_cpg<T, 2>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
-    default: launch_fwd_cpg<T, 4>(p, x, in_aff, wp, bias, z, partials, B, H, W, Cin, Cout, st); break;
+    case 1: launch_fwd_cpg<T, 1>(p, a, st); break;
+    case 2: launch_fwd_cpg<T, 2>(p, a, st); break;
+    default: launch_fwd_cpg<T, 4>(p, a, st); break;
   }
   MIS_CHECK_LAUNCH("conv3x3_mfma_kernel");
   if (stats) {
-    launch_reduce_partials(partials, p.grid_x, 2 * Cout, stats, st);
+    launch_reduce_partials(a.partials, p.grid_x, 2 * Cout, stats, st);
     MIS_CHECK_LAUNCH("reduce_partials_kernel");
   }
   return MIS_OK;
@@ -580,6 +620,19 @@ int run_fwd(const void* x, const float* in_aff, const void* wp, const float* bia
 bool conv3x3_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout) {
   FwdPlan p;
   return dtype == MIS_BF16 ? plan_fwd<bf16>(B, H, W, Cin, Cout, p) : plan_fwd<float>(B, H, W, Cin, Cout, p);
+}
+
+bool conv3x3_mfma_cat_supported(int dtype, int Ca, int Cb, int Cout) {
+  FwdPlan p;
+  if (Ca != Cb) return false;
+  return dtype == MIS_BF16 ? plan_fwd<bf16>(1, 16, 16, Ca + Cb, Cout, p, Ca, -1)
+                           : plan_fwd<float>(1, 16, 16, Ca + Cb, Cout, p, Ca, -1);
+}
+
+bool conv3x3_mfma_split_supported(int dtype, int Cin, int Ca, int Cb) {
+  FwdPlan p;
+  return dtype == MIS_BF16 ? plan_fwd<bf16>(1, 16, 16, Cin, Ca + Cb, p, -1, Ca)
+                           : plan_fwd<float>(1, 16, 16, Cin, Ca + Cb, p, -1, Ca);
 }
 
 size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout) {
@@ -611,10 +664,10 @@ int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int
   return MIS_OK;
 }
 
-int conv3x3_mfma_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
-                     int W, int Cin, int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
-  if (dtype == MIS_BF16) return run_fwd<bf16>(x, in_aff, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
-  return run_fwd<float>(x, in_aff, wp, bias, B, H, W, Cin, Cout, z, stats, workspace, st);
+int conv3x3_mfma_fwd(const ConvIn& in, const void* wp, const float* bias, int dtype, int B, int H, int W,
+                     const ConvOut& out, float* stats, void* workspace, hipStream_t st) {
+  if (dtype == MIS_BF16) return run_fwd<bf16>(in, wp, bias, B, H, W, out, stats, workspace, st);
+  return run_fwd<float>(in, wp, bias, B, H, W, out, stats, workspace, st);
 }
 
 // =====================================================================================
@@ -670,11 +723,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int lane_of
 }
 
 template <typename T, int MTO, int NTI, int WCO, int WCI, int WK>
-__global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dz,
-                                                                 float* __restrict__ slab, int B, int H, int W,
-                                                                 int Cin, int Cout, int n_ci_blocks, int tiles_x,
-                                                                 int tiles_y, int n_tiles,
-                                                                 const float* __restrict__ x_aff) {
+__global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel(
+    const T* __restrict__ xa, const T* __restrict__ xb, int Ca, const T* __restrict__ dz, float* __restrict__ slab,
+    int B, int H, int W, int Cin, int Cout, int n_ci_blocks, int tiles_x, int tiles_y, int n_tiles,
+    const float* __restrict__ affa, const float* __restrict__ affb) {
   constexpr int NTHR = 64 * WCO * WCI * WK;
   constexpr int G = Mf<T>::G;
   constexpr int TH = WgT<T>::TH;
@@ -696,6 +748,12 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel
   const int wk = wid % WK, wci = (wid / WK) % WCI, wco = wid / (WK * WCI);
   const int cib = blockIdx.y % n_ci_blocks, cob = blockIdx.y / n_ci_blocks;
   const int ci0 = cib * CTI, co0 = cob * CTO;
+  // two-tensor input [xa (Ca channels) | xb]: this workgroup's channel tile lies in one of them
+  const bool sb = xb != nullptr && ci0 >= Ca;
+  const T* const x = sb ? xb : xa;
+  const float* const x_aff = sb ? affb : affa;
+  const int Csrc = xb == nullptr ? Cin : (sb ? Cin - Ca : Ca);     // channels (= pixel stride) of that tensor
+  const int cl0 = sb ? ci0 - Ca : ci0;                              // first channel of the tile inside it
 
   f32x4 acc[9][MTO][NTI];
 #pragma unroll
@@ -707,7 +765,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel
 
   u32x4 xr[XIT], zr[ZIT];
   constexpr int OOB = 0x7FFFFFFF;
-  const int ximg_bytes = H * W * Cin * (int)sizeof(T), zimg_bytes = H * W * Cout * (int)sizeof(T);
+  const int ximg_bytes = H * W * Csrc * (int)sizeof(T), zimg_bytes = H * W * Cout * (int)sizeof(T);
   // buffer loads: out-of-range offsets (padding, tile tails, channel tails, dead stages) read zeros
 #define WG_LOAD(TILE, LIVE)                                                                             \
   {                                                                                                     \
@@ -716,17 +774,17 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel
     const int tx_ = t_ % tiles_x, ty_ = (t_ / tiles_x) % tiles_y, b_ = t_ / (tiles_x * tiles_y);        \
     const int y0_ = ty_ * TH, x0_ = tx_ * WG_TW;                                                        \
     const __amdgpu_buffer_rsrc_t xrs_ = __builtin_amdgcn_make_buffer_rsrc(                              \
-        (void*)(x + (int64_t)b_ * H * W * Cin), 0, ximg_bytes, 0x00020000);                             \
+        (void*)(x + (int64_t)b_ * H * W * Csrc), 0, ximg_bytes, 0x00020000);                            \
     const __amdgpu_buffer_rsrc_t zrs_ = __builtin_amdgcn_make_buffer_rsrc(                              \
         (void*)(dz + (int64_t)b_ * H * W * Cout), 0, zimg_bytes, 0x00020000);                           \
     _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                   \
       const int v = tid + i * NTHR;                                                                      \
       const int pos = v / XVP, cv = v % XVP;                                                            \
       const int gy = y0_ - 1 + pos / HWW, gx = x0_ - 1 + pos % HWW;                                     \
-      const int c = ci0 + cv * G;                                                                       \
-      const bool ok = live_ && (v < XV) && gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cin;           \
+      const int c = cl0 + cv * G;                                                                       \
+      const bool ok = live_ && (v < XV) && gy >= 0 && gy < H && gx >= 0 && gx < W && c < Csrc;          \
       xr[i] = __builtin_amdgcn_raw_buffer_load_b128(                                                    \
-          xrs_, ok ? ((gy * W + gx) * Cin + c) * (int)sizeof(T) : OOB, 0, 0);                           \
+          xrs_, ok ? ((gy * W + gx) * Csrc + c) * (int)sizeof(T) : OOB, 0, 0);                          \
     }                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < ZIT; i++) {                                                   \
       const int v = tid + i * NTHR;                                                                      \
@@ -748,7 +806,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel
       u32x4 val = xr[i];                                                                                \
       if (x_aff) {                                                                                      \
         const int gy = y0_ + pos / HWW, gx = x0_ + pos % HWW;                                           \
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W && ci0 + cv * G < Cin)                               \
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W && cl0 + cv * G < Csrc)                              \
           val = affine_relu_raw<T>(val, aff + cv * G, aff + CTI + cv * G);                              \
       }                                                                                                 \
       if (v < XV) *reinterpret_cast<u32x4*>(xh + pos * RSX + cv * 16) = val;                            \
@@ -767,8 +825,8 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK) void conv3x3_wgrad_mfma_kernel
 
   if (x_aff) {
     for (int i = tid; i < 2 * CTI; i += NTHR) {
-      const int c = ci0 + i % CTI;
-      aff[i] = (c < Cin) ? x_aff[(i / CTI) * Cin + c] : 0.f;
+      const int c = cl0 + i % CTI;
+      aff[i] = (c < Csrc) ? x_aff[(i / CTI) * Csrc + c] : 0.f;
     }
   }
   int tile = blockIdx.x;
@@ -905,7 +963,7 @@ struct WgPlan {
 };
 
 template <typename T>
-bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p) {
+bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1) {
   constexpr int G = Mf<T>::G;
   constexpr int TH = WgT<T>::TH;
   if (Cin % G != 0 || Cout % G != 0) return false;
@@ -914,6 +972,7 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p) {
   else if (Cout > 16) { p.cfg = 1; p.CTO = 32; p.CTI = 16; }
   else if (Cin > 16) { p.cfg = 2; p.CTO = 16; p.CTI = 32; }
   else { p.cfg = 0; p.CTO = 16; p.CTI = 16; }
+  if (Ca >= 0 && Ca != Cin && (Ca <= 0 || Ca % p.CTI != 0)) return false;   // channel tiles must not straddle the two inputs
   p.n_co_blocks = (Cout + p.CTO - 1) / p.CTO;
   p.n_ci_blocks = (Cin + p.CTI - 1) / p.CTI;
   p.tiles_x = (W + WG_TW - 1) / WG_TW;
@@ -942,10 +1001,11 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p) {
 }
 
 template <typename T>
-int run_wgrad(const void* x, const float* x_aff, const void* dz, int B, int H, int W, int Cin, int Cout, float* dw,
-              void* workspace, hipStream_t st) {
+int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, float* dw, void* workspace,
+              hipStream_t st) {
   WgPlan p;
-  if (!plan_wgrad<T>(B, H, W, Cin, Cout, p)) {
+  const int Cin = in.channels();
+  if (!plan_wgrad<T>(B, H, W, Cin, Cout, p, in.Ca)) {
     mis_set_error("conv3x3_wgrad_mfma: unsupported shape Cin=%d Cout=%d", Cin, Cout);
     return MIS_ERR_UNSUPPORTED;
   }
@@ -956,8 +1016,9 @@ int run_wgrad(const void* x, const float* x_aff, const void* dz, int B, int H, i
     auto kfn = conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK>;                                       \
     if (p.lds > 48 * 1024)                                                                                 \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
-    kfn<<<grid, 64 * WCO * WCI * WK, p.lds, st>>>((const T*)x, (const T*)dz, slab, B, H, W, Cin, Cout,     \
-                                                  p.n_ci_blocks, p.tiles_x, p.tiles_y, p.n_tiles, x_aff);  \
+    kfn<<<grid, 64 * WCO * WCI * WK, p.lds, st>>>((const T*)in.xa, (const T*)in.xb, in.Ca, (const T*)dz, slab, B, \
+                                                  H, W, Cin, Cout, p.n_ci_blocks, p.tiles_x, p.tiles_y,    \
+                                                  p.n_tiles, in.affa, in.affb);                            \
   }
   switch (p.cfg) {
     case 0: WG_LAUNCH(1, 1, 1, 1, 4); break;
@@ -993,8 +1054,14 @@ size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Ci
   return align256((size_t)p.nsplit * 9 * Cin * Cout * sizeof(float));
 }
 
-int conv3x3_wgrad_mfma(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
-                       int Cout, float* dw, void* workspace, hipStream_t st) {
-  if (dtype == MIS_BF16) return run_wgrad<bf16>(x, x_aff, dz, B, H, W, Cin, Cout, dw, workspace, st);
-  return run_wgrad<float>(x, x_aff, dz, B, H, W, Cin, Cout, dw, workspace, st);
+bool conv3x3_wgrad_mfma_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout) {
+  WgPlan p;
+  return dtype == MIS_BF16 ? plan_wgrad<bf16>(B, H, W, Ca + Cb, Cout, p, Ca)
+                           : plan_wgrad<float>(B, H, W, Ca + Cb, Cout, p, Ca);
+}
+
+int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, float* dw,
+                       void* workspace, hipStream_t st) {
+  if (dtype == MIS_BF16) return run_wgrad<bf16>(in, dz, B, H, W, Cout, dw, workspace, st);
+  return run_wgrad<float>(in, dz, B, H, W, Cout, dw, workspace, st);
 }

@@ -140,29 +140,63 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None):
-    """z = conv3x3(act(x)) + bias; optionally the per-channel (sum, sumsq) of z.
-    act(x) = relu(x*scale + shift) when x_ss ([2, Cin]) is given (lazy activation), else x."""
-    B, Cin, H, W = x.shape
+def cat_supported(x, x2, Cout):
+    """Whether conv / data gradient / weight gradient can treat [x | x2] as one concatenated input
+    without materialising it (else the caller concatenates)."""
+    B, Ca, H, W = x.shape
+    return bool(query("mis_conv3x3_cat_supported", _dt(x), B, H, W, Ca, x2.shape[1], Cout))
+
+
+def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None, x2=None, x2_ss=None):
+    """z = conv3x3(act([x | x2])) + bias; optionally the per-channel (sum, sumsq) of z.
+    act(t) = relu(t*scale + shift) per tensor when its ss ([2, C]) is given (lazy activation),
+    else t.  x2 (optional) supplies the input channels after x's: the concatenation is virtual."""
+    B, Ca, H, W = x.shape
+    Cb = x2.shape[1] if x2 is not None else 0
+    Cin = Ca + Cb
     z = _empty_act(B, Cout, H, W, x)
     stats = torch.empty((2, Cout), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Cout), x.device)
     es = x.element_size()
     with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, (B * H * W * (Cin + Cout) + 9 * Cin * Cout) * es):
-        call("mis_conv3x3_fwd", x.data_ptr(), _p(x_ss), w_packed.data_ptr(), _p(bias),
-             _dt(x), B, H, W, Cin, Cout, z.data_ptr(), _p(stats), ws.data_ptr(), _stream())
+        if x2 is None:
+            call("mis_conv3x3_fwd", x.data_ptr(), _p(x_ss), w_packed.data_ptr(), _p(bias),
+                 _dt(x), B, H, W, Cin, Cout, z.data_ptr(), _p(stats), ws.data_ptr(), _stream())
+        else:
+            call("mis_conv3x3_cat_fwd", x.data_ptr(), _p(x_ss), x2.data_ptr(), _p(x2_ss), w_packed.data_ptr(),
+                 _p(bias), _dt(x), B, H, W, Ca, Cb, Cout, z.data_ptr(), _p(stats), ws.data_ptr(), _stream())
     return z, stats
 
 
-def conv3x3_wgrad_raw(x, dz, x_ss=None):
+def conv3x3_split_raw(x, w_packed, Ca, Cb):
+    """The conv of conv3x3_raw (no bias, no statistics) with its output channels written as two
+    tensors [0, Ca) and [Ca, Ca+Cb): the data gradient of a conv over a virtual concatenation."""
     B, Cin, H, W = x.shape
+    za, zb = _empty_act(B, Ca, H, W, x), _empty_act(B, Cb, H, W, x)
+    ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Ca + Cb), x.device)
+    es = x.element_size()
+    with _prof("conv3x3_fwd", 18 * B * H * W * Cin * (Ca + Cb),
+               (B * H * W * (Cin + Ca + Cb) + 9 * Cin * (Ca + Cb)) * es):
+        call("mis_conv3x3_split_fwd", x.data_ptr(), None, w_packed.data_ptr(), None, _dt(x), B, H, W, Cin, Ca, Cb,
+             za.data_ptr(), zb.data_ptr(), ws.data_ptr(), _stream())
+    return za, zb
+
+
+def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None):
+    B, Ca, H, W = x.shape
+    Cb = x2.shape[1] if x2 is not None else 0
+    Cin = Ca + Cb
     Cout = dz.shape[1]
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
     ws = workspace(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), x.device)
     with _prof("conv3x3_wgrad", 18 * B * H * W * Cin * Cout,
                B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout):
-        call("mis_conv3x3_wgrad", x.data_ptr(), _p(x_ss), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout, dw.data_ptr(),
-             ws.data_ptr(), _stream())
+        if x2 is None:
+            call("mis_conv3x3_wgrad", x.data_ptr(), _p(x_ss), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout,
+                 dw.data_ptr(), ws.data_ptr(), _stream())
+        else:
+            call("mis_conv3x3_cat_wgrad", x.data_ptr(), _p(x_ss), x2.data_ptr(), _p(x2_ss), dz.data_ptr(), _dt(x),
+                 B, H, W, Ca, Cb, Cout, dw.data_ptr(), ws.data_ptr(), _stream())
     return dw
 
 
@@ -185,15 +219,23 @@ class ConvBnReluFn(torch.autograd.Function):
     into `z` is the gradient with respect to the ACTIVATION."""
 
     @staticmethod
-    def forward(ctx, x, x_ss, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps, momentum):
+    def forward(ctx, x, x_ss, x2, x2_ss, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps,
+                momentum):
+        """x2 (optional, lazy or plain like x): the input is the virtual concatenation [x | x2]."""
         _check_act(x)
-        B, Cin, H, W = x.shape
+        B, Ca, H, W = x.shape
+        Cin = Ca
+        if x2 is not None:
+            _check_act(x2, "x2")
+            if x2.shape[0] != B or x2.shape[2:] != x.shape[2:] or x2.dtype != x.dtype:
+                raise ValueError(f"x2 {tuple(x2.shape)} does not match x {tuple(x.shape)}")
+            Cin += x2.shape[1]
         Cout = weight.shape[0]
         if weight.shape != (Cout, Cin, 3, 3):
             raise ValueError(f"weight {tuple(weight.shape)} does not match input channels {Cin}")
         n_pix = B * H * W
         wf = pack_weights(weight.detach(), x.dtype)
-        z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout, training, x_ss)
+        z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout, training, x_ss, x2, x2_ss)
         ss = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         mr = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         st = _stream()
@@ -207,7 +249,7 @@ class ConvBnReluFn(torch.autograd.Function):
                  beta.data_ptr(), Cout, eps, ss.data_ptr(), st)
             mr[0].copy_(running_mean)
             mr[1].copy_(torch.rsqrt(running_var + eps))
-        ctx.save_for_backward(x, x_ss, z, weight, gamma, beta, mr)
+        ctx.save_for_backward(x, x_ss, x2, x2_ss, z, weight, gamma, beta, mr)
         ctx.training = training
         ctx.has_bias = bias is not None
         ctx.mark_non_differentiable(ss)
@@ -215,9 +257,9 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, da, _dss):
-        x, x_ss, z, weight, gamma, beta, mr = ctx.saved_tensors
-        B, Cin, H, W = x.shape
-        Cout = weight.shape[0]
+        x, x_ss, x2, x2_ss, z, weight, gamma, beta, mr = ctx.saved_tensors
+        B, Ca, H, W = x.shape
+        Cout, Cin = weight.shape[0], weight.shape[1]
         n_pix = B * H * W
         da = to_act(da, x.dtype)
         st = _stream()
@@ -230,17 +272,20 @@ class ConvBnReluFn(torch.autograd.Function):
         # eval mode: statistics are constants, so the two projection terms vanish
         proj = sums if ctx.training else torch.zeros_like(sums)
         dz = torch.empty_like(z)
-        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        want_db = ctx.has_bias and ctx.needs_input_grad[5]
         dbias = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
         with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
             call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
                  gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(), _p(dbias), ws.data_ptr(), st)
-        dx = None
-        if ctx.needs_input_grad[0]:
+        dx = dx2 = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
             wd = pack_weights(weight.detach(), x.dtype, transposed=True)
-            dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
-        dw = conv3x3_wgrad_raw(x, dz, x_ss) if ctx.needs_input_grad[2] else None
-        return dx, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
+            if x2 is None:
+                dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
+            else:
+                dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
+        dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss) if ctx.needs_input_grad[4] else None
+        return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
 class MaterializeFn(torch.autograd.Function):
@@ -264,11 +309,12 @@ def materialize(t, ss):
     return t if ss is None else MaterializeFn.apply(t, ss)
 
 
-def conv_bn_relu(x, x_ss, conv, bn, training):
-    """(x, x_ss) -> lazy (z, ss) with the parameters of an nn.Conv2d / nn.BatchNorm2d pair."""
+def conv_bn_relu(x, x_ss, conv, bn, training, x2=None, x2_ss=None):
+    """(x, x_ss) [| (x2, x2_ss)] -> lazy (z, ss) with the parameters of an nn.Conv2d /
+    nn.BatchNorm2d pair; with x2 the conv input is the virtual concatenation [x | x2]."""
     momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
-    return ConvBnReluFn.apply(x, x_ss, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                              bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum))
+    return ConvBnReluFn.apply(x, x_ss, x2, x2_ss, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                              bn.running_var, bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum))
 
 
 # ---------------------------------------------------------------------------
@@ -363,6 +409,32 @@ class UpsampleCatFn(torch.autograd.Function):
             call("mis_upsample2x_cat_bwd", dout.data_ptr(), _dt(dout), B, h, w, Cup, Cskip, dlow.data_ptr(),
                  dskip.data_ptr(), _stream())
         return dlow, None, dskip, None
+
+
+class UpsampleFn(torch.autograd.Function):
+    """bilinear x2 (align_corners=True) of a lazy or plain activation — unet.py:20,66 — for the
+    decoder convs that read [up | skip] as two tensors."""
+
+    @staticmethod
+    def forward(ctx, low, low_ss):
+        _check_act(low, "low")
+        B, Cup, h, w = low.shape
+        out = _empty_act(B, Cup, 2 * h, 2 * w, low)
+        with _prof("upsample2x_cat_fwd", 0, (low.numel() + out.numel()) * low.element_size()):
+            call("mis_upsample2x_cat_fwd", low.data_ptr(), _p(low_ss), None, None, _dt(low), B, h, w, Cup, 0,
+                 out.data_ptr(), _stream())
+        ctx.dims = (B, h, w, Cup)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, h, w, Cup = ctx.dims
+        dout = to_act(dout)
+        dlow = _empty_act(B, Cup, h, w, dout)
+        with _prof("upsample2x_cat_bwd", 0, (dout.numel() + dlow.numel()) * dout.element_size()):
+            call("mis_upsample2x_cat_bwd", dout.data_ptr(), _dt(dout), B, h, w, Cup, 0, dlow.data_ptr(), None,
+                 _stream())
+        return dlow, None
 
 
 class Conv1x1Fn(torch.autograd.Function):

@@ -77,11 +77,21 @@ class UNet(nn.Module):
         p4, z4 = down(z4, s4)
         x5 = drop(self.encoder_dropout4, p4)
         y, sy = self._lazy_drop(self.bottleneck_dropout, *self.center_conv.forward_lazy(x5))
-        y, sy = self._lazy_drop(self.decoder_dropout1, *self.decoder1.forward_lazy(upcat(y, sy, z4, s4)))
-        y, sy = self._lazy_drop(self.decoder_dropout2, *self.decoder2.forward_lazy(upcat(y, sy, z3, s3)))
-        y, sy = self.decoder3.forward_lazy(upcat(y, sy, z2, s2))
-        y, sy = self.decoder4.forward_lazy(upcat(y, sy, z1, s1))
+        y, sy = self._lazy_drop(self.decoder_dropout1, *self._up(self.decoder1, y, sy, z4, s4))
+        y, sy = self._lazy_drop(self.decoder_dropout2, *self._up(self.decoder2, y, sy, z3, s3))
+        y, sy = self._up(self.decoder3, y, sy, z2, s2)
+        y, sy = self._up(self.decoder4, y, sy, z1, s1)
         return F_.Conv1x1Fn.apply(y, sy, self.out_conv.weight, self.out_conv.bias)
+
+    @staticmethod
+    def _up(block, low, low_ss, skip, skip_ss):
+        """x = up(low); x = cat([x, skip], 1); x = block(x) — unet.py:66-68.  Where the conv
+        kernels take two input tensors the concatenation is virtual: only the upsampled half is
+        written, the skip is read in place (lazily) by the conv and its weight gradient, and the
+        data gradient comes back as two tensors."""
+        if F_.cat_supported(skip, skip, block.cbr1[0].out_channels) and low.shape[1] == skip.shape[1]:
+            return block.forward_lazy(F_.UpsampleFn.apply(low, low_ss), None, skip, skip_ss)
+        return block.forward_lazy(F_.UpsampleCatFn.apply(low, low_ss, skip, skip_ss))
 
     @staticmethod
     def _lazy_drop(layer, z, ss):

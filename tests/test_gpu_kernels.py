@@ -530,3 +530,82 @@ def test_conv3x3_wgrad_mfma_vs_direct_and_oracle(F_, dtype, shape, lazy):
         assert dw.shape == (Co, Ci, 3, 3)
         assert rel_err(dw, wo.grad) < tol
     assert rel_err(outs[0], outs[1]) < tol
+
+
+# ---------------------------------------------------------------------------
+# virtual concatenation: conv / data gradient / weight gradient over [xa | xb]
+# ---------------------------------------------------------------------------
+CAT_SHAPES = [  # B, Ca (= Cb), Cout, H, W
+    (1, 32, 8, 16, 16), (2, 64, 32, 20, 12), (1, 32, 64, 16, 16), (1, 128, 16, 8, 8), (1, 64, 128, 16, 32),
+    (2, 32, 40, 18, 34)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", CAT_SHAPES)
+@pytest.mark.parametrize("lazy", [(False, False), (False, True), (True, True)])
+def test_conv3x3_virtual_concat(F_, dtype, shape, lazy):
+    """The two-tensor entry points against the one-tensor ones on the materialised concatenation
+    (same kernels, same summation order: bitwise equal), and against the float64 oracle."""
+    B, Ca, Co, H, W = shape
+    xa, xb = dg.hash_normalish((B, Ca, H, W), 901), dg.hash_normalish((B, Ca, H, W), 902)
+    w = dg.hash_normalish((Co, 2 * Ca, 3, 3), 903, std=(2.0 / (18 * Ca)) ** 0.5)
+    b = dg.hash_uniform((Co,), 904, -0.1, 0.1)
+    gz = dg.hash_normalish((B, Co, H, W), 905)
+    ssa = lazy_pair(Ca, 910) if lazy[0] else None
+    ssb = lazy_pair(Ca, 920) if lazy[1] else None
+    xad, xbd, gd = act(xa, dtype), act(xb, dtype), act(gz, dtype)
+    if not F_.cat_supported(xad, xbd, Co):
+        pytest.skip("shape not taken by the two-tensor kernels in this dtype")
+    dev = lambda t: t.to(DEV) if t is not None else None
+    # the materialised concatenation the one-tensor path sees: values of both halves, plain
+    va = q(lazy_value(xa, ssa, dtype), dtype) if lazy[0] else q(xa, dtype)
+    vb = q(lazy_value(xb, ssb, dtype), dtype) if lazy[1] else q(xb, dtype)
+    cat = act(torch.cat([va, vb], dim=1), dtype)
+    wd, bd = T(w).to(DEV), T(b).to(DEV)
+    wf, wt = F_.pack_weights(wd, dtype), F_.pack_weights(wd, dtype, transposed=True)
+    z2, st2 = F_.conv3x3_raw(xad, wf, bd, Co, True, dev(ssa), xbd, dev(ssb))
+    z1, st1 = F_.conv3x3_raw(cat, wf, bd, Co, True)
+    assert torch.equal(z2, z1) and torch.equal(st2, st1)
+    da, db = F_.conv3x3_split_raw(gd, wt, Ca, Ca)
+    d1, _ = F_.conv3x3_raw(gd, wt, None, 2 * Ca, False)
+    assert torch.equal(da, d1[:, :Ca]) and torch.equal(db, d1[:, Ca:])
+    dw2 = F_.conv3x3_wgrad_raw(xad, gd, dev(ssa), xbd, dev(ssb))
+    dw1 = F_.conv3x3_wgrad_raw(cat, gd)
+    assert torch.equal(dw2, dw1)
+    # oracle
+    xo = torch.cat([va, vb], dim=1).double().requires_grad_(True)
+    wo = q(w, dtype).double().requires_grad_(True)
+    zo = torch.nn.functional.conv2d(xo, wo, T(b).double(), padding=1)
+    zo.backward(q(gz, dtype).double())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(z2, zo) < tol
+    assert rel_err(torch.cat([da, db], dim=1), xo.grad) < tol
+    assert rel_err(dw2, wo.grad) < (2e-5 if dtype == torch.float32 else 3e-3)
+
+
+def test_double_conv_two_inputs_matches_concat(F_):
+    """DoubleConv over (up, skip) as two tensors == DoubleConv over their concatenation, forward
+    and every gradient (float32, the Up block of unet.py:66-68)."""
+    from medical_image_segmentation_amd.model.utils.modules import DoubleConv
+    B, Ca, Co, H, W = 2, 32, 32, 16, 16
+    xa, xb = dg.hash_normalish((B, Ca, H, W), 931), dg.hash_normalish((B, Ca, H, W), 932)
+    gy = dg.hash_normalish((B, Co, H, W), 933)
+    ssb = lazy_pair(Ca, 934).to(DEV)
+    m = DoubleConv(2 * Ca, Co).to(DEV).train()
+    xad, xbd = act(xa).requires_grad_(True), act(xb).requires_grad_(True)
+    assert F_.cat_supported(xad, xbd, m.cbr1[0].out_channels)
+    y = F_.materialize(*m.forward_lazy(xad, None, xbd, ssb))
+    y.backward(act(gy))
+    g2 = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    xa1 = act(xa).requires_grad_(True)
+    vb = F_.materialize(act(xb), ssb).detach().requires_grad_(True)
+    for bn in (m.cbr1[1], m.cbr2[1]):
+        bn.reset_running_stats()
+    y1 = m(torch.cat([xa1, vb], dim=1).contiguous(memory_format=torch.channels_last))
+    y1.backward(act(gy))
+    assert rel_err(y, y1) < 1e-6
+    assert rel_err(xad.grad, xa1.grad) < 1e-5
+    assert rel_err(xbd.grad, vb.grad) < 1e-5      # gradient with respect to the skip's VALUE
+    for a, b_ in zip(g2, [p.grad for p in m.parameters()]):
+        assert rel_err(a, b_) < 1e-5
