@@ -132,55 +132,191 @@ __device__ __forceinline__ void up_taps(int dst, float scale, int n_in, int& i0,
   l0 = 1.0f - l1;
 }
 
-template <typename T, int V>
-__global__ __launch_bounds__(EW_THREADS) void upcat_fwd_kernel(const T* __restrict__ low, const T* __restrict__ skip,
-                                                               T* __restrict__ out, int B, int h, int w, int Cup,
-                                                               int Cskip, float sy, float sx,
-                                                               const float* __restrict__ low_aff,
-                                                               const float* __restrict__ skip_aff) {
-  extern __shared__ float aff_lds[];              // [2][Cup] then [2][Cskip]
-  const float *affl = nullptr, *affs = nullptr;
+// ---- bilinear x2 upsampling, tiled through LDS ------------------------------------------
+// Forward: a workgroup owns a 16x16 output tile and a chunk of UP_CC channels.  The <= 10x10
+// low-resolution pixels the tile interpolates from are loaded once, the producer's lazy
+// affine + ReLU is applied to each of them ONCE (not once per output tap), and they are kept in
+// LDS in the storage type; every output then blends 4 LDS vectors.  `Cdst` is the channel count
+// of the destination pixel (== C, or C + Cskip when the result is the head of a concatenation).
+constexpr int UP_T = 16;          // output tile edge
+constexpr int UP_SRC = 10;        // max low-res rows/cols under a tile: floor(15*s)+2 with s < 1/2
+
+template <typename T, int CC>
+__global__ __launch_bounds__(EW_THREADS) void up_fwd_tiled_kernel(const T* __restrict__ low, T* __restrict__ out,
+                                                                  int B, int h, int w, int C, int Cdst, float sy,
+                                                                  float sx, int tiles_x, int tiles_y,
+                                                                  const float* __restrict__ low_aff) {
+  constexpr int G = 16 / (int)sizeof(T);        // channels per 16-byte vector
+  constexpr int VC = CC / G;                    // vectors per pixel in this chunk
+  constexpr int PITCH = VC * 16 + 16;           // LDS bytes per staged pixel (padded: odd number of 16-byte slots)
+  __shared__ __attribute__((aligned(16))) unsigned char tile[UP_SRC * UP_SRC * PITCH];
+  __shared__ float affl[2 * CC];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.y * CC;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+  const int Ho = 2 * h, Wo = 2 * w, Y0 = ty * UP_T, X0 = tx * UP_T;
+  int ya, xa, i1;
+  float l0, l1;
+  up_taps(Y0, sy, h, ya, i1, l0, l1);
+  up_taps(X0, sx, w, xa, i1, l0, l1);
   if (low_aff) {
-    for (int i = threadIdx.x; i < 2 * Cup; i += EW_THREADS) aff_lds[i] = low_aff[i];
-    affl = aff_lds;
+    for (int i = tid; i < 2 * CC; i += EW_THREADS) {
+      const int c = c0 + i % CC;
+      affl[i] = (c < C) ? low_aff[(i / CC) * C + c] : 0.f;
+    }
+    __syncthreads();
   }
-  if (skip_aff) {
-    for (int i = threadIdx.x; i < 2 * Cskip; i += EW_THREADS) aff_lds[2 * Cup + i] = skip_aff[i];
-    affs = aff_lds + 2 * Cup;
+  // stage the source pixels (rows ya.., cols xa.., clipped to the image)
+  const T* src = low + (int64_t)b * h * w * C;
+  for (int i = tid; i < UP_SRC * UP_SRC * VC; i += EW_THREADS) {
+    const int cv = i % VC, pos = i / VC;
+    const int r = pos / UP_SRC, c = pos % UP_SRC;
+    const int gy = ya + r, gx = xa + c, ch = c0 + cv * G;
+    if (gy < h && gx < w && ch < C) {
+      float v[G];
+      vload<T, G>(src + ((int64_t)gy * w + gx) * C + ch, v);
+      affine_relu<G>(v, low_aff ? affl : nullptr, CC, cv * G);
+      vstore<T, G>(reinterpret_cast<T*>(tile + pos * PITCH + cv * 16), v);
+    }
   }
-  if (low_aff || skip_aff) __syncthreads();
-  const int Ho = 2 * h, Wo = 2 * w, Ct = Cup + Cskip, CV = Ct / V, CVup = Cup / V;
-  const int64_t total = (int64_t)B * Ho * Wo * CV;
+  __syncthreads();
+  // 256 threads = (256 / VC) pixels per pass; a thread keeps its column and channel vector
+  constexpr int PPP = EW_THREADS / VC;          // pixels per pass
+  static_assert(PPP % UP_T == 0 || UP_T % PPP == 0, "pass shape");
+  const int cv = tid % VC, pp = tid / VC;
+  for (int p0 = 0; p0 < UP_T * UP_T; p0 += PPP) {
+    const int pix = p0 + pp, oy = pix / UP_T, ox = pix % UP_T;
+    const int Y = Y0 + oy, X = X0 + ox, ch = c0 + cv * G;
+    if (Y >= Ho || X >= Wo || ch >= C) continue;
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    up_taps(Y, sy, h, y0, y1, hy0, hy1);
+    up_taps(X, sx, w, x0, x1, wx0, wx1);
+    const unsigned char* tb = tile + cv * 16;
+    float a[G], bq[G], c[G], d[G], r[G];
+    vload<T, G>(reinterpret_cast<const T*>(tb + ((y0 - ya) * UP_SRC + (x0 - xa)) * PITCH), a);
+    vload<T, G>(reinterpret_cast<const T*>(tb + ((y0 - ya) * UP_SRC + (x1 - xa)) * PITCH), bq);
+    vload<T, G>(reinterpret_cast<const T*>(tb + ((y1 - ya) * UP_SRC + (x0 - xa)) * PITCH), c);
+    vload<T, G>(reinterpret_cast<const T*>(tb + ((y1 - ya) * UP_SRC + (x1 - xa)) * PITCH), d);
+#pragma unroll
+    for (int k = 0; k < G; k++) r[k] = hy0 * (wx0 * a[k] + wx1 * bq[k]) + hy1 * (wx0 * c[k] + wx1 * d[k]);
+    vstore<T, G>(out + (((int64_t)b * Ho + Y) * Wo + X) * Cdst + ch, r);
+  }
+}
+
+// Backward (transposed interpolation) in gather form.  With scale (n-1)/(2n-1) < 1/2 the taps
+// of output row Y are floor(Y*s) and the row after it, so low-resolution row r only receives
+// from output rows 2r-1 .. 2r+2 (4 candidates; checked exhaustively for n <= 4096).  A workgroup
+// owns an 8x8 low-resolution tile and a chunk of channels, stages the 18x18 high-resolution
+// gradient pixels that can touch it (rows/cols 2*first-1 .. 2*first+16) in LDS, and every
+// low-resolution pixel sums its <= 16 contributions in a fixed order (bitwise reproducible).
+// `Csrc` is the channel count of a source pixel (== C, or C + Cskip when the gradient is the head
+// of a concatenation's).
+constexpr int UPB_T = 8;
+constexpr int UPB_K = 4;                       // candidate rows/cols per low-resolution pixel
+constexpr int UPB_SRC = 2 * UPB_T + UPB_K - 2;
+
+template <typename T, int CC>
+__global__ __launch_bounds__(EW_THREADS) void up_bwd_tiled_kernel(const T* __restrict__ dout, T* __restrict__ dlow,
+                                                                  int B, int h, int w, int C, int Csrc, float sy,
+                                                                  float sx, int tiles_x, int tiles_y) {
+  constexpr int G = 16 / (int)sizeof(T);
+  constexpr int VC = CC / G;
+  constexpr int PITCH = VC * 16 + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char btile[];      // [UPB_SRC*UPB_SRC][PITCH]
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.y * CC;
+  const int t = blockIdx.x;
+  const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+  const int Ho = 2 * h, Wo = 2 * w;
+  const int yl0 = ty * UPB_T, xl0 = tx * UPB_T, YA = 2 * yl0 - 1, XA = 2 * xl0 - 1;
+  const T* src = dout + (int64_t)b * Ho * Wo * Csrc;
+  for (int i = tid; i < UPB_SRC * UPB_SRC * VC; i += EW_THREADS) {
+    const int cv = i % VC, pos = i / VC;
+    const int Y = YA + pos / UPB_SRC, X = XA + pos % UPB_SRC, ch = c0 + cv * G;
+    if (Y >= 0 && Y < Ho && X >= 0 && X < Wo && ch < C)
+      *reinterpret_cast<uint4*>(btile + pos * PITCH + cv * 16) =
+          *reinterpret_cast<const uint4*>(src + ((int64_t)Y * Wo + X) * Csrc + ch);
+  }
+  __syncthreads();
+  for (int i = tid; i < UPB_T * UPB_T * VC; i += EW_THREADS) {
+    const int cv = i % VC, pix = i / VC;
+    const int yl = yl0 + pix / UPB_T, xl = xl0 + pix % UPB_T, ch = c0 + cv * G;
+    if (yl >= h || xl >= w || ch >= C) continue;
+    float wy[UPB_K], wxv[UPB_K];
+#pragma unroll
+    for (int k = 0; k < UPB_K; k++) {
+      int i0, i1;
+      float l0, l1;
+      const int Y = 2 * yl - 1 + k;
+      float wgt = 0.f;
+      if (Y >= 0 && Y < Ho) {
+        up_taps(Y, sy, h, i0, i1, l0, l1);
+        wgt = ((i0 == yl) ? l0 : 0.f) + ((i1 == yl) ? l1 : 0.f);
+      }
+      wy[k] = wgt;
+      const int X = 2 * xl - 1 + k;
+      wgt = 0.f;
+      if (X >= 0 && X < Wo) {
+        up_taps(X, sx, w, i0, i1, l0, l1);
+        wgt = ((i0 == xl) ? l0 : 0.f) + ((i1 == xl) ? l1 : 0.f);
+      }
+      wxv[k] = wgt;
+    }
+    float acc[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) acc[k] = 0.f;
+    // staged position of candidate (ky, kx): (2*(yl-yl0) + ky, 2*(xl-xl0) + kx)
+    const unsigned char* tb = btile + ((2 * (yl - yl0)) * UPB_SRC + 2 * (xl - xl0)) * PITCH + cv * 16;
+#pragma unroll
+    for (int ky = 0; ky < UPB_K; ky++) {
+      if (wy[ky] == 0.f) continue;            // also skips rows outside the image (never staged)
+      float row[G];
+#pragma unroll
+      for (int k = 0; k < G; k++) row[k] = 0.f;
+#pragma unroll
+      for (int kx = 0; kx < UPB_K; kx++) {
+        if (wxv[kx] == 0.f) continue;
+        float g[G];
+        vload<T, G>(reinterpret_cast<const T*>(tb + (ky * UPB_SRC + kx) * PITCH), g);
+#pragma unroll
+        for (int k = 0; k < G; k++) row[k] += wxv[kx] * g[k];
+      }
+#pragma unroll
+      for (int k = 0; k < G; k++) acc[k] += wy[ky] * row[k];
+    }
+    vstore<T, G>(dlow + (((int64_t)b * h + yl) * w + xl) * C + ch, acc);
+  }
+}
+
+// Scalar fallbacks (channel counts that are not a multiple of the 16-byte vector).
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void up_fwd_scalar_kernel(const T* __restrict__ low, T* __restrict__ out,
+                                                                   int B, int h, int w, int C, int Cdst, float sy,
+                                                                   float sx, const float* __restrict__ low_aff) {
+  const int Ho = 2 * h, Wo = 2 * w;
+  const int64_t total = (int64_t)B * Ho * Wo * C;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
-    const int cv = (int)(i % CV);
-    int64_t p = i / CV;
+    const int c = (int)(i % C);
+    int64_t p = i / C;
     const int xo = (int)(p % Wo);
     p /= Wo;
     const int yo = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    float r[V];
-    if (cv < CVup) {
-      int y0, y1, x0, x1;
-      float hy0, hy1, wx0, wx1;
-      up_taps(yo, sy, h, y0, y1, hy0, hy1);
-      up_taps(xo, sx, w, x0, x1, wx0, wx1);
-      const T* base = low + (int64_t)b * h * w * Cup + cv * V;
-      float a[V], bq[V], c[V], d[V];
-      vload<T, V>(base + ((int64_t)y0 * w + x0) * Cup, a);
-      vload<T, V>(base + ((int64_t)y0 * w + x1) * Cup, bq);
-      vload<T, V>(base + ((int64_t)y1 * w + x0) * Cup, c);
-      vload<T, V>(base + ((int64_t)y1 * w + x1) * Cup, d);
-      affine_relu<V>(a, affl, Cup, cv * V);
-      affine_relu<V>(bq, affl, Cup, cv * V);
-      affine_relu<V>(c, affl, Cup, cv * V);
-      affine_relu<V>(d, affl, Cup, cv * V);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    up_taps(yo, sy, h, y0, y1, hy0, hy1);
+    up_taps(xo, sx, w, x0, x1, wx0, wx1);
+    const T* base = low + (int64_t)b * h * w * C + c;
+    float v[4] = {to_f32(base[((int64_t)y0 * w + x0) * C]), to_f32(base[((int64_t)y0 * w + x1) * C]),
+                  to_f32(base[((int64_t)y1 * w + x0) * C]), to_f32(base[((int64_t)y1 * w + x1) * C])};
+    if (low_aff) {
 #pragma unroll
-      for (int k = 0; k < V; k++) r[k] = hy0 * (wx0 * a[k] + wx1 * bq[k]) + hy1 * (wx0 * c[k] + wx1 * d[k]);
-    } else {
-      vload<T, V>(skip + (((int64_t)b * Ho + yo) * Wo + xo) * Cskip + (cv - CVup) * V, r);
-      affine_relu<V>(r, affs, Cskip, (cv - CVup) * V);
+      for (int k = 0; k < 4; k++) v[k] = to_f32(from_f32<T>(fmaxf(v[k] * low_aff[c] + low_aff[C + c], 0.f)));
     }
-    vstore<T, V>(out + i * V, r);
+    out[(((int64_t)b * Ho + yo) * Wo + xo) * Cdst + c] =
+        from_f32<T>(hy0 * (wx0 * v[0] + wx1 * v[1]) + hy1 * (wx0 * v[2] + wx1 * v[3]));
   }
 }
 
@@ -245,18 +381,21 @@ __global__ __launch_bounds__(EW_THREADS) void up_bwd_kernel(const T* __restrict_
   }
 }
 
-// dskip[pix][0:Cskip] = dout[pix][Cup:Cup+Cskip]
+// dst[pix][d0 : d0+Cs] = act(src[pix][s0 : s0+Cs]) between tensors of Cdst / Csrc channels per
+// pixel (the skip half of a concatenation and the slice of its gradient).
 template <typename T, int V>
-__global__ __launch_bounds__(EW_THREADS) void slice_channels_kernel(const T* __restrict__ src, T* __restrict__ dst,
-                                                                    int64_t n_pix, int Ct, int c0, int Cs) {
+__global__ __launch_bounds__(EW_THREADS) void copy_channels_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                                   int64_t n_pix, int Csrc, int s0, int Cdst, int d0,
+                                                                   int Cs, const float* __restrict__ aff) {
   const int CV = Cs / V;
   const int64_t total = n_pix * CV;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
     const int cv = (int)(i % CV);
     const int64_t p = i / CV;
     float v[V];
-    vload<T, V>(src + p * Ct + c0 + cv * V, v);
-    vstore<T, V>(dst + i * V, v);
+    vload<T, V>(src + p * Csrc + s0 + cv * V, v);
+    affine_relu<V>(v, aff, Cs, cv * V);
+    vstore<T, V>(dst + p * Cdst + d0 + cv * V, v);
   }
 }
 
@@ -294,15 +433,36 @@ int upcat_fwd(const void* low, const void* skip, void* out, int B, int h, int w,
               const float* low_aff, const float* skip_aff, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int Ct = Cup + Cskip;
-  const int64_t n = (int64_t)B * 4 * h * w * Ct;
   const bool vec = (Cup % N == 0) && (Cskip % N == 0) && pick_vec<T>(Ct, low, skip, out) == N;
-  const size_t lds = (low_aff || skip_aff) ? 2 * (size_t)Ct * sizeof(float) : 0;
-  if (vec)
-    upcat_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>(
-        (const T*)low, (const T*)skip, (T*)out, B, h, w, Cup, Cskip, up_scale(h), up_scale(w), low_aff, skip_aff);
-  else
-    upcat_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>(
-        (const T*)low, (const T*)skip, (T*)out, B, h, w, Cup, Cskip, up_scale(h), up_scale(w), low_aff, skip_aff);
+  if (vec) {
+    const int tiles_x = (2 * w + UP_T - 1) / UP_T, tiles_y = (2 * h + UP_T - 1) / UP_T;
+    // channel chunk per workgroup: 128 bytes of a pixel, or 64 when that leaves no idle lanes
+    if (Cup % (8 * N) == 0) {
+      constexpr int CC = 8 * N;
+      dim3 grid(B * tiles_x * tiles_y, Cup / CC);
+      up_fwd_tiled_kernel<T, CC><<<grid, EW_THREADS, 0, st>>>((const T*)low, (T*)out, B, h, w, Cup, Ct, up_scale(h),
+                                                              up_scale(w), tiles_x, tiles_y, low_aff);
+    } else {
+      constexpr int CC = 4 * N;
+      dim3 grid(B * tiles_x * tiles_y, (Cup + CC - 1) / CC);
+      up_fwd_tiled_kernel<T, CC><<<grid, EW_THREADS, 0, st>>>((const T*)low, (T*)out, B, h, w, Cup, Ct, up_scale(h),
+                                                              up_scale(w), tiles_x, tiles_y, low_aff);
+    }
+  } else {
+    const int64_t n = (int64_t)B * 4 * h * w * Cup;
+    up_fwd_scalar_kernel<T><<<ew_grid(n, EW_THREADS), EW_THREADS, 0, st>>>((const T*)low, (T*)out, B, h, w, Cup, Ct,
+                                                                           up_scale(h), up_scale(w), low_aff);
+  }
+  if (Cskip > 0) {
+    const int64_t npix = (int64_t)B * 4 * h * w;
+    const size_t lds = 0;
+    if (vec)
+      copy_channels_kernel<T, N><<<ew_grid(npix * Cskip / N, EW_THREADS), EW_THREADS, lds, st>>>(
+          (const T*)skip, (T*)out, npix, Cskip, 0, Ct, Cup, Cskip, skip_aff);
+    else
+      copy_channels_kernel<T, 1><<<ew_grid(npix * Cskip, EW_THREADS), EW_THREADS, lds, st>>>(
+          (const T*)skip, (T*)out, npix, Cskip, 0, Ct, Cup, Cskip, skip_aff);
+  }
   return 0;
 }
 
@@ -314,17 +474,28 @@ int upcat_bwd(const void* dout, void* dlow, void* dskip, int B, int h, int w, in
   const int64_t nl = (int64_t)B * h * w * Cup;
   const int64_t npix = (int64_t)B * 4 * h * w;
   if (vec) {
-    up_bwd_kernel<T, N><<<ew_grid(nl / N, EW_THREADS), EW_THREADS, 0, st>>>((const T*)dout, (T*)dlow, B, h, w, Cup, Ct,
-                                                                              up_scale(h), up_scale(w));
+    const int tiles_x = (w + UPB_T - 1) / UPB_T, tiles_y = (h + UPB_T - 1) / UPB_T;
+    // channel chunk per workgroup: 128 bytes of a pixel when the channel count allows, else 64
+    if (Cup % (8 * N) == 0) {
+      constexpr int CC = 8 * N;
+      const size_t lds = (size_t)UPB_SRC * UPB_SRC * (CC / N * 16 + 16);
+      up_bwd_tiled_kernel<T, CC><<<dim3(B * tiles_x * tiles_y, Cup / CC), EW_THREADS, lds, st>>>(
+          (const T*)dout, (T*)dlow, B, h, w, Cup, Ct, up_scale(h), up_scale(w), tiles_x, tiles_y);
+    } else {
+      constexpr int CC = 4 * N;
+      const size_t lds = (size_t)UPB_SRC * UPB_SRC * (CC / N * 16 + 16);
+      up_bwd_tiled_kernel<T, CC><<<dim3(B * tiles_x * tiles_y, (Cup + CC - 1) / CC), EW_THREADS, lds, st>>>(
+          (const T*)dout, (T*)dlow, B, h, w, Cup, Ct, up_scale(h), up_scale(w), tiles_x, tiles_y);
+    }
     if (dskip && Cskip > 0)
-      slice_channels_kernel<T, N><<<ew_grid(npix * Cskip / N, EW_THREADS), EW_THREADS, 0, st>>>(
-          (const T*)dout, (T*)dskip, npix, Ct, Cup, Cskip);
+      copy_channels_kernel<T, N><<<ew_grid(npix * Cskip / N, EW_THREADS), EW_THREADS, 0, st>>>(
+          (const T*)dout, (T*)dskip, npix, Ct, Cup, Cskip, 0, Cskip, nullptr);
   } else {
     up_bwd_kernel<T, 1><<<ew_grid(nl, EW_THREADS), EW_THREADS, 0, st>>>((const T*)dout, (T*)dlow, B, h, w, Cup, Ct,
                                                                           up_scale(h), up_scale(w));
     if (dskip && Cskip > 0)
-      slice_channels_kernel<T, 1><<<ew_grid(npix * Cskip, EW_THREADS), EW_THREADS, 0, st>>>(
-          (const T*)dout, (T*)dskip, npix, Ct, Cup, Cskip);
+      copy_channels_kernel<T, 1><<<ew_grid(npix * Cskip, EW_THREADS), EW_THREADS, 0, st>>>(
+          (const T*)dout, (T*)dskip, npix, Ct, Cup, Cskip, 0, Cskip, nullptr);
   }
   return 0;
 }
@@ -369,7 +540,7 @@ int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const void*
   else if (dtype == MIS_BF16)
     upcat_fwd<bf16>(low, skip, out, B, h, w, Cup, Cskip, low_affine, skip_affine, (hipStream_t)stream);
   else MIS_REQUIRE(false, "upsample2x_cat_fwd: bad dtype %d", dtype);
-  MIS_CHECK_LAUNCH("upcat_fwd_kernel");
+  MIS_CHECK_LAUNCH("up_fwd_tiled_kernel");
   return MIS_OK;
 }
 
@@ -380,7 +551,7 @@ int mis_upsample2x_cat_bwd(const void* dout, int dtype, int B, int h, int w, int
   if (dtype == MIS_F32) upcat_bwd<float>(dout, dlow, dskip, B, h, w, Cup, Cskip, (hipStream_t)stream);
   else if (dtype == MIS_BF16) upcat_bwd<bf16>(dout, dlow, dskip, B, h, w, Cup, Cskip, (hipStream_t)stream);
   else MIS_REQUIRE(false, "upsample2x_cat_bwd: bad dtype %d", dtype);
-  MIS_CHECK_LAUNCH("up_bwd_kernel");
+  MIS_CHECK_LAUNCH("up_bwd_tiled_kernel");
   return MIS_OK;
 }
 
