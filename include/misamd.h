@@ -126,6 +126,10 @@ int mis_upsample2x_cat_bwd(const void* dout, int dtype, int B, int h, int w, int
 size_t mis_conv3x3_packed_weight_bytes(int Cout_w, int Cin_w, int transposed, int dtype);
 int mis_pack_conv3x3_weights(const float* w, int Cout_w, int Cin_w, int transposed, int dtype, void* out,
                              mis_stream_t stream);
+/* Both images of one weight tensor (transposed = 0 into out_fwd, transposed = 1 */
+/* into out_t) in one launch where the kernel family allows.                     */
+int mis_pack_conv3x3_weights_pair(const float* w, int Cout_w, int Cin_w, int dtype, void* out_fwd, void* out_t,
+                                  mis_stream_t stream);
 /* Test hook: 0 = pick the kernel per shape (default), 1 = vector-ALU kernels only.   */
 /* Weights must be re-packed after a change.                                          */
 int mis_set_conv_path(int mode);
@@ -136,7 +140,11 @@ int mis_set_conv_path(int mode);
 /* it needs the workspace.  Used for the forward conv (transposed=0 image,       */
 /* Cin->Cout) and, with the transposed=1 image and the channel counts swapped,  */
 /* for the data gradient.                                                       */
+/* Passing stats == workspace skips the final reduction: the workspace then     */
+/* starts with mis_conv3x3_stats_rows(...) rows of partial sums [rows][2][Cout]   */
+/* for mis_bn_finalize to reduce (one launch fewer per layer).                    */
 size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int mis_conv3x3_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout);
 int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype,
                     int B, int H, int W, int Cin, int Cout,
                     void* z, float* stats, void* workspace, mis_stream_t stream);
@@ -172,13 +180,15 @@ int mis_conv3x3_cat_wgrad(const void* xa, const float* xa_affine, const void* xb
                           float* dw, void* workspace, mis_stream_t stream);
 
 /* Training-mode BatchNorm2d statistics -> per-channel affine + running stats.   */
-/* stats float32 [2][C] (sum, sum of squares over n = B*H*W values per channel). */
+/* stats float32 [stats_rows][2][C]: (sum, sum of squares over n = B*H*W values   */
+/* per channel), either reduced (stats_rows = 1) or as the per-workgroup partial  */
+/* rows a conv launch leaves in its workspace (summed here in a fixed order).     */
 /* scale_shift float32 [2][C]: y = z*scale + shift with                          */
 /*   scale = gamma / sqrt(var_biased + eps), shift = beta - mean*scale.           */
 /* mean_rstd float32 [2][C] saved for the backward.  running_mean/var (may be    */
 /* NULL) are updated with `momentum` and the UNBIASED variance, as               */
 /* nn.BatchNorm2d does; num_batches_tracked (int64[1], may be NULL) += 1.        */
-int mis_bn_finalize(const float* stats, int C, int64_t n, const float* gamma, const float* beta,
+int mis_bn_finalize(const float* stats, int stats_rows, int C, int64_t n, const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float* scale_shift, float* mean_rstd, mis_stream_t stream);
 /* Eval-mode affine from the running statistics.                                 */

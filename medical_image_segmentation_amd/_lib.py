@@ -36,6 +36,8 @@ PROTOTYPES = {
     "mis_pack_conv3x3_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mis_set_conv_path": (_i, [_i]),
     "mis_conv3x3_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "mis_conv3x3_stats_rows": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mis_pack_conv3x3_weights_pair": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mis_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mis_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -43,7 +45,7 @@ PROTOTYPES = {
     "mis_conv3x3_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_split_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_cat_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "mis_bn_finalize": (_i, [_vp, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_finalize": (_i, [_vp, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_eval_affine": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     "mis_bn_relu_apply": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_workspace_bytes": (_sz, [_i64, _i]),

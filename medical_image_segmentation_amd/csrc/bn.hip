@@ -52,16 +52,41 @@ inline int grid_for_fixed_channels(int want, int CV, int cap) {
   return grid < g ? g : grid;
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double inv_n, double unbias,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   int64_t* __restrict__ nbt, float* __restrict__ scale_shift,
-                                   float* __restrict__ mean_rstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) nbt[0] += 1;
-  if (c >= C) return;
-  const double mean = (double)stats[c] * inv_n;
-  double var = (double)stats[C + c] * inv_n - mean * mean;
+// stats: [rows][2][C] partial (sum, sum of squares); rows == 1 is the reduced form.  32 row
+// lanes x 32 channels per workgroup, double accumulation, fixed order (bitwise reproducible).
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int rows, int C,
+                                                           double inv_n, double unbias,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                           float* __restrict__ scale_shift,
+                                                           float* __restrict__ mean_rstd) {
+  __shared__ double red[2][32][33];
+  const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int i = r; i < rows; i += 32) {
+      s1 += (double)stats[(int64_t)i * 2 * C + c];
+      s2 += (double)stats[(int64_t)i * 2 * C + C + c];
+    }
+  }
+  red[0][r][cl] = s1;
+  red[1][r][cl] = s2;
+  __syncthreads();
+  if (r != 0 || c >= C) return;
+  s1 = s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 32; k++) {
+    s1 += red[0][k][cl];
+    s2 += red[1][k][cl];
+  }
+  // the conv kernels hand over float32 sums; keep the reduced sums' float32 rounding so that the
+  // one-row and the many-row forms give identical results
+  const double mean = (double)(float)s1 * inv_n;
+  double var = (double)(float)s2 * inv_n - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * rstd;
@@ -282,15 +307,17 @@ int chan_sum_t(const void* x, int64_t n_pix, int C, float* out, void* ws, hipStr
 
 extern "C" {
 
-int mis_bn_finalize(const float* stats, int C, int64_t n, const float* gamma, const float* beta, float eps,
-                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                    float* scale_shift, float* mean_rstd, mis_stream_t stream) {
+int mis_bn_finalize(const float* stats, int stats_rows, int C, int64_t n, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, float* scale_shift, float* mean_rstd, mis_stream_t stream) {
   MIS_REQUIRE(stats && gamma && beta && scale_shift, "bn_finalize: null pointer");
-  MIS_REQUIRE(C >= 1 && n >= 1, "bn_finalize: bad shape C=%d n=%lld", C, (long long)n);
+  MIS_REQUIRE(C >= 1 && n >= 1 && stats_rows >= 1, "bn_finalize: bad shape C=%d n=%lld rows=%d", C, (long long)n,
+              stats_rows);
   const double unbias = n > 1 ? (double)n / (double)(n - 1) : 1.0;
-  bn_finalize_kernel<<<cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(stats, C, 1.0 / (double)n, unbias, gamma, beta,
-                                                                    eps, momentum, running_mean, running_var,
-                                                                    num_batches_tracked, scale_shift, mean_rstd);
+  bn_finalize_kernel<<<cdiv(C, 32), 1024, 0, (hipStream_t)stream>>>(stats, stats_rows, C, 1.0 / (double)n, unbias,
+                                                                    gamma, beta, eps, momentum, running_mean,
+                                                                    running_var, num_batches_tracked, scale_shift,
+                                                                    mean_rstd);
   MIS_CHECK_LAUNCH("bn_finalize_kernel");
   return MIS_OK;
 }

@@ -47,6 +47,22 @@ int mis_pack_conv3x3_weights(const float* w, int Cout_w, int Cin_w, int transpos
   return conv3x3_direct_pack(w, Cout_w, Cin_w, transposed ? 1 : 0, dtype, out, (hipStream_t)stream);
 }
 
+int mis_pack_conv3x3_weights_pair(const float* w, int Cout_w, int Cin_w, int dtype, void* out_fwd, void* out_t,
+                                  mis_stream_t stream) {
+  MIS_REQUIRE(w && out_fwd && out_t && Cout_w >= 1 && Cin_w >= 1, "pack_conv3x3_weights_pair: bad arguments");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "pack_conv3x3_weights_pair: bad dtype %d", dtype);
+  if (use_mfma(dtype, Cin_w, Cout_w) && use_mfma(dtype, Cout_w, Cin_w))
+    return conv3x3_mfma_pack_pair(w, Cout_w, Cin_w, dtype, out_fwd, out_t, (hipStream_t)stream);
+  const int rc = mis_pack_conv3x3_weights(w, Cout_w, Cin_w, 0, dtype, out_fwd, stream);
+  return rc != MIS_OK ? rc : mis_pack_conv3x3_weights(w, Cout_w, Cin_w, 1, dtype, out_t, stream);
+}
+
+int mis_conv3x3_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
+  return use_mfma(dtype, Cin, Cout) ? conv3x3_mfma_stats_rows(dtype, B, H, W, Cin, Cout)
+                                    : conv3x3_direct_stats_rows((int64_t)B * H * W);
+}
+
 size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
   size_t a = conv3x3_direct_workspace_bytes((int64_t)B * H * W, Cout);

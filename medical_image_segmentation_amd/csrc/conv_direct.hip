@@ -397,6 +397,11 @@ size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout) {
   return align256((size_t)CD_MAX_BLOCKS * 2 * Cout * sizeof(float));
 }
 
+int conv3x3_direct_stats_rows(int64_t n_pix) {
+  int gx = cdiv(n_pix, CD_THREADS);
+  return gx > CD_MAX_BLOCKS ? CD_MAX_BLOCKS : gx;
+}
+
 int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
                        int W, int Cin, int Cout, void* z, float* stats, void* workspace, hipStream_t st) {
   const int64_t n_pix = (int64_t)B * H * W;
@@ -420,7 +425,7 @@ int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const
                                                                    partials, B, H, W, Cin, Cout, in_aff);
   }
   MIS_CHECK_LAUNCH("conv3x3_direct_kernel");
-  if (stats) {
+  if (stats && (void*)stats != workspace) {      // stats == workspace: the caller reduces the partial rows itself
     launch_reduce_partials(partials, grid.x, 2 * Cout, stats, st);
     MIS_CHECK_LAUNCH("reduce_partials_kernel");
   }

@@ -3,6 +3,10 @@
 #include "common.h"
 
 size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout);
+// Rows of per-workgroup partial statistics [rows][2][Cout] a forward launch leaves at the start
+// of the workspace (reduced into `stats` unless stats == workspace).
+int conv3x3_direct_stats_rows(int64_t n_pix);
+int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout);
 // `in_aff` / `x_aff`: optional [2][Cin] (scale, shift) of a lazily stored input activation:
 // the kernel reads relu(x*scale + shift) instead of x (padding stays zero).
 int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
@@ -38,6 +42,8 @@ int conv3x3_mfma_fwd(const ConvIn& in, const void* wp, const float* bias, int dt
                      const ConvOut& out, float* stats, void* workspace, hipStream_t st);
 size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
+// both images (forward and transposed = data-gradient operand) of one weight tensor in one launch
+int conv3x3_mfma_pack_pair(const float* w, int Cw_out, int Cw_in, int dtype, void* out_fwd, void* out_t, hipStream_t st);
 bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
 size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
 bool conv3x3_wgrad_mfma_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout);

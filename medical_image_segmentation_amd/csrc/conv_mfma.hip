@@ -84,29 +84,36 @@ __device__ __forceinline__ int halo_addr(int p, int cg) { return p * halo_pstrid
 
 // Packed weight layout: [chunk][step][n-tile (16 couts)][lane 0..63][G elements]; lane l holds
 // W[cout = 16n + (l&15)][k-group 4*step + (l>>4)], group -> (tap, cg) = (g / CPG, g % CPG).
+// One launch packs one image, or (total2 > 0) both: elements [0, total) of the `transposed`
+// image into out, then elements of the other orientation into out2.
 template <typename T>
 __global__ void pack_w3x3_frag_kernel(const float* __restrict__ w, int Cw_out, int Cw_in, int transposed,
-                                      int CPG, int n_chunks, int nt_total, T* __restrict__ out) {
+                                      int CPG, int n_chunks, int nt_total, T* __restrict__ out, int64_t total,
+                                      int CPG2, int n_chunks2, int nt_total2, T* __restrict__ out2, int64_t total2) {
   constexpr int G = Mf<T>::G;
-  const int NS = (9 * CPG + 3) / 4;
-  const int64_t total = (int64_t)n_chunks * NS * nt_total * 64 * G;
-  const int Cout = transposed ? Cw_in : Cw_out;     // channels the conv produces
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total + total2;
+       i0 += (int64_t)gridDim.x * blockDim.x) {
+    const bool second = i0 >= total;
+    const int64_t i = second ? i0 - total : i0;
+    const int tr = second ? !transposed : transposed;
+    const int cpg = second ? CPG2 : CPG, ntt = second ? nt_total2 : nt_total;
+    const int NS = (9 * cpg + 3) / 4;
+    const int Cout = tr ? Cw_in : Cw_out;     // channels the conv produces
     const int j = (int)(i % G);
     const int l = (int)((i / G) % 64);
-    const int n = (int)((i / (G * 64)) % nt_total);
-    const int s = (int)((i / ((int64_t)G * 64 * nt_total)) % NS);
-    const int c = (int)(i / ((int64_t)G * 64 * nt_total * NS));
+    const int n = (int)((i / (G * 64)) % ntt);
+    const int s = (int)((i / ((int64_t)G * 64 * ntt)) % NS);
+    const int c = (int)(i / ((int64_t)G * 64 * ntt * NS));
     const int g = 4 * s + (l >> 4);
-    const int tap = g / CPG, cg = g % CPG;
+    const int tap = g / cpg, cg = g % cpg;
     const int co = 16 * n + (l & 15);
-    const int ci = (c * CPG + cg) * G + j;
+    const int ci = (c * cpg + cg) * G + j;
     float v = 0.f;
     if (tap < 9 && co < Cout) {
-      if (!transposed) v = w[((int64_t)co * Cw_in + ci) * 9 + tap];
+      if (!tr) v = w[((int64_t)co * Cw_in + ci) * 9 + tap];
       else v = w[((int64_t)ci * Cw_in + co) * 9 + (8 - tap)];
     }
-    out[i] = from_f32<T>(v);
+    (second ? out2 : out)[i] = from_f32<T>(v);
   }
 }
 
@@ -608,7 +615,7 @@ int run_fwd(const ConvIn& in, const void* wp, const float* bias, int B, int H, i
     default: launch_fwd_cpg<T, 4>(p, a, st); break;
   }
   MIS_CHECK_LAUNCH("conv3x3_mfma_kernel");
-  if (stats) {
+  if (stats && (void*)stats != workspace) {      // stats == workspace: the caller reduces the partial rows itself
     launch_reduce_partials(a.partials, p.grid_x, 2 * Cout, stats, st);
     MIS_CHECK_LAUNCH("reduce_partials_kernel");
   }
@@ -635,6 +642,12 @@ bool conv3x3_mfma_split_supported(int dtype, int Cin, int Ca, int Cb) {
                            : plan_fwd<float>(1, 16, 16, Cin, Ca + Cb, p, -1, Ca);
 }
 
+int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout) {
+  FwdPlan p;
+  const bool ok = dtype == MIS_BF16 ? plan_fwd<bf16>(B, H, W, Cin, Cout, p) : plan_fwd<float>(B, H, W, Cin, Cout, p);
+  return ok ? p.grid_x : 0;
+}
+
 size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout) {
   return align256((size_t)8192 * 2 * Cout * sizeof(float));
 }
@@ -647,19 +660,49 @@ size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout) {
   return (size_t)n_chunks * nsteps_of(CPG) * ((Cout + 15) / 16) * 1024;
 }
 
-int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st) {
-  const int Cin = transposed ? Cw_out : Cw_in, Cout = transposed ? Cw_in : Cw_out;   // conv roles
+namespace {
+struct PackGeom {
+  int CPG, n_chunks, nt_total;
+  int64_t total;
+};
+PackGeom pack_geom(int Cin, int Cout, int dtype) {
   const int G = dtype == MIS_BF16 ? 8 : 4;
   const int groups = Cin / G;
-  const int CPG = groups <= 4 ? groups : 4;
-  const int n_chunks = groups <= 4 ? 1 : groups / 4;
-  const int nt_total = (Cout + 15) / 16;
-  const int64_t total = (int64_t)n_chunks * nsteps_of(CPG) * nt_total * 64 * G;
-  const int grid = ew_grid(total, 256);
+  PackGeom g;
+  g.CPG = groups <= 4 ? groups : 4;
+  g.n_chunks = groups <= 4 ? 1 : groups / 4;
+  g.nt_total = (Cout + 15) / 16;
+  g.total = (int64_t)g.n_chunks * nsteps_of(g.CPG) * g.nt_total * 64 * G;
+  return g;
+}
+}  // namespace
+
+int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st) {
+  const int Cin = transposed ? Cw_out : Cw_in, Cout = transposed ? Cw_in : Cw_out;   // conv roles
+  const PackGeom g = pack_geom(Cin, Cout, dtype);
+  const int grid = ew_grid(g.total, 256);
   if (dtype == MIS_BF16)
-    pack_w3x3_frag_kernel<bf16><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, transposed, CPG, n_chunks, nt_total, (bf16*)out);
+    pack_w3x3_frag_kernel<bf16><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, transposed, g.CPG, g.n_chunks, g.nt_total,
+                                                       (bf16*)out, g.total, 0, 0, 0, (bf16*)nullptr, 0);
   else
-    pack_w3x3_frag_kernel<float><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, transposed, CPG, n_chunks, nt_total, (float*)out);
+    pack_w3x3_frag_kernel<float><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, transposed, g.CPG, g.n_chunks, g.nt_total,
+                                                        (float*)out, g.total, 0, 0, 0, (float*)nullptr, 0);
+  MIS_CHECK_LAUNCH("pack_w3x3_frag_kernel");
+  return MIS_OK;
+}
+
+int conv3x3_mfma_pack_pair(const float* w, int Cw_out, int Cw_in, int dtype, void* out_fwd, void* out_t,
+                           hipStream_t st) {
+  const PackGeom f = pack_geom(Cw_in, Cw_out, dtype), t = pack_geom(Cw_out, Cw_in, dtype);
+  const int grid = ew_grid(f.total + t.total, 256);
+  if (dtype == MIS_BF16)
+    pack_w3x3_frag_kernel<bf16><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, 0, f.CPG, f.n_chunks, f.nt_total,
+                                                       (bf16*)out_fwd, f.total, t.CPG, t.n_chunks, t.nt_total,
+                                                       (bf16*)out_t, t.total);
+  else
+    pack_w3x3_frag_kernel<float><<<grid, 256, 0, st>>>(w, Cw_out, Cw_in, 0, f.CPG, f.n_chunks, f.nt_total,
+                                                        (float*)out_fwd, f.total, t.CPG, t.n_chunks, t.nt_total,
+                                                        (float*)out_t, t.total);
   MIS_CHECK_LAUNCH("pack_w3x3_frag_kernel");
   return MIS_OK;
 }

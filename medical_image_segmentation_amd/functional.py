@@ -136,6 +136,19 @@ def pack_weights(w, dtype, transposed=False):
     return out
 
 
+def pack_weights_pair(w, dtype):
+    """Both operand images of one weight tensor — (forward, transposed = data-gradient operand) —
+    packed by one launch."""
+    Co, Ci = w.shape[0], w.shape[1]
+    nf = query("mis_conv3x3_packed_weight_bytes", Co, Ci, 0, _DT[dtype])
+    nt = query("mis_conv3x3_packed_weight_bytes", Co, Ci, 1, _DT[dtype])
+    nf_al = (nf + 255) // 256 * 256
+    buf = torch.empty(nf_al + nt, dtype=torch.uint8, device=w.device)
+    wf, wt = buf[:nf], buf[nf_al:]
+    call("mis_pack_conv3x3_weights_pair", w.data_ptr(), Co, Ci, _DT[dtype], wf.data_ptr(), wt.data_ptr(), _stream())
+    return wf, wt
+
+
 def _p(t):
     return t.data_ptr() if t is not None else None
 
@@ -155,8 +168,14 @@ def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None, x2=None, x2_ss=N
     Cb = x2.shape[1] if x2 is not None else 0
     Cin = Ca + Cb
     z = _empty_act(B, Cout, H, W, x)
-    stats = torch.empty((2, Cout), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Cout), x.device)
+    if want_stats == "partial":
+        # un-reduced per-workgroup rows stay at the head of the workspace for bn_finalize, which must
+        # be the next user of the workspace on this stream: (tensor, rows)
+        stats = ws
+        rows = query("mis_conv3x3_stats_rows", _dt(x), B, H, W, Cin, Cout)
+    else:
+        stats = torch.empty((2, Cout), dtype=torch.float32, device=x.device) if want_stats else None
     es = x.element_size()
     with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, (B * H * W * (Cin + Cout) + 9 * Cin * Cout) * es):
         if x2 is None:
@@ -165,7 +184,7 @@ def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None, x2=None, x2_ss=N
         else:
             call("mis_conv3x3_cat_fwd", x.data_ptr(), _p(x_ss), x2.data_ptr(), _p(x2_ss), w_packed.data_ptr(),
                  _p(bias), _dt(x), B, H, W, Ca, Cb, Cout, z.data_ptr(), _p(stats), ws.data_ptr(), _stream())
-    return z, stats
+    return z, ((stats, rows) if want_stats == "partial" else stats)
 
 
 def conv3x3_split_raw(x, w_packed, Ca, Cb):
@@ -234,15 +253,21 @@ class ConvBnReluFn(torch.autograd.Function):
         if weight.shape != (Cout, Cin, 3, 3):
             raise ValueError(f"weight {tuple(weight.shape)} does not match input channels {Cin}")
         n_pix = B * H * W
-        wf = pack_weights(weight.detach(), x.dtype)
-        z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout, training, x_ss, x2, x2_ss)
+        ctx.set_materialize_grads(False)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:      # a data gradient will be asked for
+            wf, ctx.wt = pack_weights_pair(weight.detach(), x.dtype)
+        else:
+            wf, ctx.wt = pack_weights(weight.detach(), x.dtype), None
+        z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout,
+                               "partial" if training else False, x_ss, x2, x2_ss)
         ss = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         mr = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
         st = _stream()
         if training:
             if n_pix <= 1:
                 raise ValueError("Expected more than 1 value per channel when training")
-            call("mis_bn_finalize", stats.data_ptr(), Cout, n_pix, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+            call("mis_bn_finalize", stats[0].data_ptr(), stats[1], Cout, n_pix, gamma.data_ptr(), beta.data_ptr(), eps,
+                 momentum,
                  _p(running_mean), _p(running_var), _p(nbt), ss.data_ptr(), mr.data_ptr(), st)
         else:
             call("mis_bn_eval_affine", running_mean.data_ptr(), running_var.data_ptr(), gamma.data_ptr(),
@@ -257,6 +282,8 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, da, _dss):
+        if da is None:
+            return (None,) * 14
         x, x_ss, x2, x2_ss, z, weight, gamma, beta, mr = ctx.saved_tensors
         B, Ca, H, W = x.shape
         Cout, Cin = weight.shape[0], weight.shape[1]
@@ -268,7 +295,7 @@ class ConvBnReluFn(torch.autograd.Function):
         with _prof("bn_relu_bwd_reduce", 0, 2 * z.numel() * z.element_size()):
             call("mis_bn_relu_bwd_reduce", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
                  gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ws.data_ptr(), st)
-        dgamma, dbeta = sums[1].clone(), sums[0].clone()
+        dgamma, dbeta = sums[1], sums[0]          # rows of one buffer; nothing below writes it
         # eval mode: statistics are constants, so the two projection terms vanish
         proj = sums if ctx.training else torch.zeros_like(sums)
         dz = torch.empty_like(z)
@@ -279,7 +306,7 @@ class ConvBnReluFn(torch.autograd.Function):
                  gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(), _p(dbias), ws.data_ptr(), st)
         dx = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
-            wd = pack_weights(weight.detach(), x.dtype, transposed=True)
+            wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
             if x2 is None:
                 dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
             else:
