@@ -35,8 +35,13 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-constexpr int TW = 16;                   // output tile width; tile height = 4 waves x MT rows
-constexpr int HW_ = TW + 2;              // halo width
+// Output tile: 4 waves x MT 16-pixel row segments each, arranged as MX segments side by side
+// and MT/MX rows per wave: (16/MX) rows x (16*MX) columns.  Wider tiles read longer contiguous
+// runs of a channels-last row (fewer, larger DRAM bursts) for a slightly larger halo.
+#ifndef MIS_FWD_MX
+#define MIS_FWD_MX 1
+#endif
+constexpr int fwd_mx(int nt, int cpg) { return MIS_FWD_MX; }
 constexpr int CM_THREADS = 256;
 // rows per wave: taller tiles where the register budget allows (narrow Cout, short K chunks)
 constexpr int fwd_mt(int nt, int cpg) { return 4; }   // (8-row variants measured slower: occupancy loss)
@@ -74,11 +79,14 @@ __device__ __forceinline__ u32x4 affine_relu_raw(u32x4 raw, const float* sc, con
 }
 
 // Byte address of (position p, channel group cg) inside the halo image.  A position's row is
-// padded to an odd number of 16-byte groups (16/48/48/80 bytes for 1..4 groups), so the 16
-// lanes of one ds_read_b128 service group (16 consecutive positions, one group) fall into 16
-// distinct bank quads, and every fragment address is lane_base + a compile-time offset.
+// padded so that one ds_read_b128 is conflict-free while every fragment address stays
+// lane_base + a compile-time offset.  The hardware serves a b128 read in four groups of 16
+// lanes: lanes {0-3, 12-15} of one 16-lane row together with lanes {4-11} of the next row.  With
+// 4 groups per position (64 bytes) a 96-byte pitch puts the 8 positions of a row's part on the
+// 8 even 16-byte slots of the 256-byte bank window and the other row's (channel group + 1) on
+// the 8 odd ones; 1..3 groups use an odd multiple of 16 bytes (16/48/48).
 template <int CPG>
-constexpr int halo_pstride() { return (CPG | 1) * 16; }
+constexpr int halo_pstride() { return CPG == 4 ? 96 : (CPG | 1) * 16; }
 template <int CPG>
 __device__ __forceinline__ int halo_addr(int p, int cg) { return p * halo_pstride<CPG>() + cg * 16; }
 
@@ -158,8 +166,10 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   constexpr int NS = nsteps_of(CPG);
   constexpr int KC = CPG * G;
   constexpr int MT = fwd_mt(NT, CPG);      // tile rows per wave
-  constexpr int TH = 4 * MT;               // tile height
-  constexpr int HP = (TH + 2) * HW_;       // halo positions
+  constexpr int MX = fwd_mx(NT, CPG), MY = MT / MX;      // a wave's segments: MY rows x MX side by side
+  constexpr int TW = 16 * MX, TH = 4 * MY;               // tile width, height
+  constexpr int HW_ = TW + 2;                            // halo width
+  constexpr int HP = (TH + 2) * HW_;                     // halo positions
   constexpr int HALO_VECS = HP * CPG;
   constexpr int HALO_IT = (HALO_VECS + CM_THREADS - 1) / CM_THREADS;
   constexpr int W_VECS = NS * NT * 64;
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     }
   }
   // LDS byte address of this lane's first fragment: wave's first row, lane's column (and group)
-  const int frag_base = halo_addr<CPG>(wid * MT * HW_ + col, CPG == 4 ? kg : 0);
+  const int frag_base = halo_addr<CPG>(wid * MY * HW_ + col, CPG == 4 ? kg : 0);
 
   // tile-invariant staging state of this lane's halo elements: kept in registers, except in
   // the widest variant (no registers to spare) which recomputes it per stage
@@ -234,9 +244,9 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     if constexpr (PAIR) co = (n0 + 2 * j) * 16 + ((kg & 1) ? 16 + 4 * (kg - 1) : 4 * kg);
     else co = (n0 + j) * 16 + 4 * kg;
     const int cl = co - (zsel ? Cout_a : 0);
-    z_rel[j] = (co < Cout) ? (unsigned)((((wid * MT) * W + col) * Cz + cl) * (int)sizeof(T)) : OOB;
+    z_rel[j] = (co < Cout) ? (unsigned)((((wid * MY) * W + col) * Cz + cl) * (int)sizeof(T)) : OOB;
   }
-  const unsigned z_row = (unsigned)(W * Cz * (int)sizeof(T));
+  const unsigned z_row = (unsigned)(W * Cz * (int)sizeof(T)), z_seg = (unsigned)(16 * Cz * (int)sizeof(T));
 
   f32x4 s1[NT], s2[NT];
 #pragma unroll
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     if (!(live && (cur.ty * TH + TH <= H) && (cur.tx * TW + TW <= W))) {                                 \
       /* partial tile (or the leading load-only iteration): pixels outside contribute nothing */         \
       _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                   \
-        pvm[m] = live && (cur.ty * TH + wid * MT + m < H) && (cur.tx * TW + col < W);                    \
+        pvm[m] = live && (cur.ty * TH + wid * MY + m / MX < H) && (cur.tx * TW + (m % MX) * 16 + col < W); \
         if (!pvm[m]) {                                                                                   \
           _Pragma("unroll") for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};          \
         }                                                                                                \
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
         (void*)(zs + (int64_t)cur.b * H * W * Cz), 0, H * W * Cz * (int)sizeof(T), 0x00020000);          \
     const unsigned zb_ = (unsigned)(((cur.ty * TH * W) + cur.tx * TW) * Cz * (int)sizeof(T));            \
     _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                     \
-      const unsigned zm_ = zb_ + (unsigned)m * z_row;                                                    \
+      const unsigned zm_ = zb_ + (unsigned)(m / MX) * z_row + (unsigned)(m % MX) * z_seg;                \
       _Pragma("unroll") for (int j = 0; j < NSTORE; j++) {                                               \
         const int off_ = (int)((pvm[m] && !(MIS_DBG & 1)) ? zm_ + z_rel[j] : OOB);                       \
         if constexpr (PAIR) {                                                                            \
@@ -393,8 +403,9 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   {                                                                                                      \
     _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                     \
       int a_;                                                                                            \
-      if constexpr (CPG == 4) a_ = frag_base + halo_addr<CPG>(m * HW_ + ((S) / 3) * HW_ + ((S) % 3), 0); \
-      else a_ = frag_base + tap_addr[CPG == 4 ? 0 : (S)] + halo_addr<CPG>(m * HW_, 0);                   \
+      const int mp_ = (m / MX) * HW_ + (m % MX) * 16;     /* segment m: row m/MX, columns 16*(m%MX).. */ \
+      if constexpr (CPG == 4) a_ = frag_base + halo_addr<CPG>(mp_ + ((S) / 3) * HW_ + ((S) % 3), 0);     \
+      else a_ = frag_base + tap_addr[CPG == 4 ? 0 : (S)] + halo_addr<CPG>(mp_, 0);                       \
       xa[BUF][m] = *reinterpret_cast<const Frag*>(halo + a_);                                            \
     }                                                                                                    \
     _Pragma("unroll") for (int n = 0; n < NT; n++)                                                       \
@@ -548,7 +559,7 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
     if (sizeof(T) == 2 && (Cout - Cout_a) % 8 != 0) p.NT = 1;
   }
   p.grid_y = p.nt_total / p.NT;
-  const int TH = 4 * fwd_mt(p.NT, p.CPG);
+  const int MX = fwd_mx(p.NT, p.CPG), TW = 16 * MX, TH = 4 * (fwd_mt(p.NT, p.CPG) / MX), HW_ = TW + 2;
   p.tiles_x = (W + TW - 1) / TW;
   p.tiles_y = (H + TH - 1) / TH;
   p.n_tiles = B * p.tiles_x * p.tiles_y;
@@ -562,7 +573,7 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
   if (gx < 256) gx = 256;
   if (gx > p.n_tiles) gx = p.n_tiles;
   p.grid_x = gx;
-  p.lds = (size_t)(TH + 2) * HW_ * ((p.CPG | 1) * 16) + 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
+  p.lds = (size_t)(TH + 2) * HW_ * (p.CPG == 4 ? 96 : (p.CPG | 1) * 16) + 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
           (size_t)p.NT * 16 * 4 + 2 * (size_t)Cin * 4;
   return true;
 }

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cat", action="store_true", help="decoder entry convs on a materialised concatenation")
     ap.add_argument("--lazy", action="store_true", help="input is a lazy activation (affine+ReLU applied on load)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -58,9 +59,19 @@ def main():
         fl = 18 * n * ci * co
         t_ideal = max(by / 6.3e12, fl / 2.5e15) * 1e6
         ss = torch.rand(2, ci, device=dev) if args.lazy else None
-        tf = timeit(lambda: F_.conv3x3_raw(x, wf, b, co, True, ss), args.iters)
-        td = timeit(lambda: F_.conv3x3_raw(dz, wd, None, ci, False), args.iters) if ci >= 8 else float("nan")
-        tw = timeit(lambda: F_.conv3x3_wgrad_raw(x, dz, ss), args.iters)
+        if name.startswith("dec") and name.endswith(".1") and not args.no_cat:
+            # decoder entry conv: [up | skip] as two tensors (skip lazy), gradient split in two
+            xa = x[:, :ci // 2].contiguous(memory_format=torch.channels_last)
+            xb = x[:, ci // 2:].contiguous(memory_format=torch.channels_last)
+            ssb = torch.rand(2, ci // 2, device=dev) if args.lazy else None
+            assert F_.cat_supported(xa, xb, co)
+            tf = timeit(lambda: F_.conv3x3_raw(xa, wf, b, co, "partial", None, xb, ssb), args.iters)
+            td = timeit(lambda: F_.conv3x3_split_raw(dz, wd, ci // 2, ci // 2), args.iters)
+            tw = timeit(lambda: F_.conv3x3_wgrad_raw(xa, dz, None, xb, ssb), args.iters)
+        else:
+            tf = timeit(lambda: F_.conv3x3_raw(x, wf, b, co, "partial", ss), args.iters)
+            td = timeit(lambda: F_.conv3x3_raw(dz, wd, None, ci, False), args.iters) if ci >= 8 else float("nan")
+            tw = timeit(lambda: F_.conv3x3_wgrad_raw(x, dz, ss), args.iters)
         f = lambda t: (by / t / 1e6, fl / t / 1e6)
         print(f"{name:8s} {ci:4d}->{co:4d} @{hw:4d} | {tf:8.1f} {f(tf)[0]:5.2f} {f(tf)[1]:6.1f} {t_ideal:6.1f} | "
               f"{td:8.1f} {f(td)[0]:5.2f} {f(td)[1]:6.1f} | {tw:8.1f} {f(tw)[0]:5.2f} {f(tw)[1]:6.1f}")
