@@ -79,6 +79,7 @@ int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, 
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_fwd: bad shape");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_fwd: bad dtype %d", dtype);
   MIS_REQUIRE((int64_t)B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < ((int64_t)1 << 40), "conv3x3_fwd: tensor too large");
+  MIS_REQUIRE((int64_t)B * H * W < ((int64_t)1 << 31), "conv3x3_fwd: B*H*W must be below 2^31");
   if (use_mfma(dtype, Cin, Cout))
     return conv3x3_mfma_fwd(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, w_packed, bias, dtype, B, H, W,
                             ConvOut{z, Cout, nullptr, 0}, stats, workspace, (hipStream_t)stream);
@@ -88,20 +89,22 @@ int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, 
 
 size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
+  size_t a = conv3x3_direct_wgrad_workspace_bytes((int64_t)B * H * W, Cin, Cout);
   size_t b = conv3x3_wgrad_mfma_workspace_bytes(MIS_BF16, B, H, W, Cin, Cout);
   size_t c = conv3x3_wgrad_mfma_workspace_bytes(MIS_F32, B, H, W, Cin, Cout);
-  return (b > c ? b : c) + 256;
+  size_t m = a > b ? a : b;
+  return (m > c ? m : c) + 256;
 }
 
 int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W, int Cin,
                       int Cout, float* dw, void* workspace, mis_stream_t stream) {
-  MIS_REQUIRE(x && dz && dw, "conv3x3_wgrad: null pointer");
+  MIS_REQUIRE(x && dz && dw && workspace, "conv3x3_wgrad: null pointer");
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_wgrad: bad shape");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_wgrad: bad dtype %d", dtype);
   if (!force_direct() && workspace && conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout))
     return conv3x3_wgrad_mfma(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, dz, dtype, B, H, W, Cout, dw, workspace,
                               (hipStream_t)stream);
-  return conv3x3_direct_wgrad(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, (hipStream_t)stream);
+  return conv3x3_direct_wgrad(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, workspace, (hipStream_t)stream);
 }
 
 int mis_conv3x3_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout) {

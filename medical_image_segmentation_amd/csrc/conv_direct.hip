@@ -66,14 +66,15 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
     __syncthreads();
   }
   // persistent walk over 256-pixel groups (trip count is block-uniform: barriers inside are safe)
-#pragma unroll 4
   for (int64_t pix0 = (int64_t)blockIdx.x * CD_THREADS; pix0 < n_pix; pix0 += (int64_t)gridDim.x * CD_THREADS) {
     const int64_t pix = pix0 + tid;
     const bool valid = pix < n_pix;
     int px = 0, py = 0;
     if (valid) {
-      px = (int)(pix % W);
-      py = (int)((pix / W) % H);
+      // 32-bit coordinates (the host checks B*H*W < 2^31): 64-bit division is emulated and slow
+      const unsigned p32 = (unsigned)pix, row = p32 / (unsigned)W;
+      px = (int)(p32 - row * (unsigned)W);
+      py = (int)(row % (unsigned)H);
     }
     float acc[CO_T];
 #pragma unroll
@@ -141,21 +142,118 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// direct 3x3 weight gradient: grid (pixel blocks, Cout/CO_T, Cin); a thread walks pixels,
-// keeps 9 x CO_T accumulators for one input channel and the block adds them atomically.
+// image-facing first layer (CIN = 1 or 3 input channels): one thread = one pixel x CO_T output
+// channels, all 9*CIN taps loaded up front (clamped address, zero selected for the padding) so
+// the loads are in flight together; weights broadcast from LDS; 16-byte coalesced stores.
+// HBM-bound on the output write.
+// ---------------------------------------------------------------------------------
+template <typename T, int CIN>
+__global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
+    const T* __restrict__ x, const T* __restrict__ wp /*[9][Cout][CIN]*/, const float* __restrict__ bias,
+    T* __restrict__ z, float* __restrict__ partials /*[gridDim.x][2][Cout] or null*/, int B, int H, int W, int Cout,
+    const float* __restrict__ in_aff) {
+  __shared__ __attribute__((aligned(16))) float wl[9 * CIN][CO_T];
+  __shared__ float red[2 * CO_T * (CD_THREADS / 64)];
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * CO_T;
+  const unsigned n_pix = (unsigned)B * H * W;
+  for (int i = tid; i < 9 * CIN * CO_T; i += CD_THREADS) {
+    const int j = i % CO_T, k = i / CO_T, ci = k % CIN, tap = k / CIN;
+    wl[k][j] = (co0 + j < Cout) ? to_f32(wp[((int64_t)tap * Cout + co0 + j) * CIN + ci]) : 0.f;
+  }
+  float bv[CO_T], st[2 * CO_T];
+#pragma unroll
+  for (int j = 0; j < CO_T; j++) {
+    bv[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
+    st[j] = st[CO_T + j] = 0.f;
+  }
+  float asc[CIN], ash[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; c++) {
+    asc[c] = in_aff ? in_aff[c] : 1.f;
+    ash[c] = in_aff ? in_aff[CIN + c] : 0.f;
+  }
+  __syncthreads();
+  const bool vec_store = (Cout % CO_T == 0) && (((uintptr_t)z & 15) == 0);
+  for (unsigned pix = blockIdx.x * CD_THREADS + tid; pix < n_pix; pix += gridDim.x * CD_THREADS) {
+    const unsigned row = pix / (unsigned)W;
+    const int px = (int)(pix - row * (unsigned)W), py = (int)(row % (unsigned)H);
+    float xv[9][CIN];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const T* xp = x + (ok ? (int64_t)pix + (tap / 3 - 1) * W + (tap % 3 - 1) : (int64_t)pix) * CIN;
+#pragma unroll
+      for (int c = 0; c < CIN; c++) {
+        float v = to_f32(xp[c]);
+        if (in_aff) v = to_f32(from_f32<T>(fmaxf(v * asc[c] + ash[c], 0.f)));
+        xv[tap][c] = ok ? v : 0.f;
+      }
+    }
+    float acc[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; j++) acc[j] = bv[j];
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; k++) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[k][0]), w1 = *reinterpret_cast<const f32x4*>(&wl[k][4]);
+      const float v = xv[k / CIN][k % CIN];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[j] += v * w0[j];
+        acc[4 + j] += v * w1[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CO_T; j++) {
+      st[j] += acc[j];
+      st[CO_T + j] += acc[j] * acc[j];
+    }
+    T* zp = z + (int64_t)pix * Cout + co0;
+    if (vec_store) {
+      if constexpr (sizeof(T) == 2) {
+        vstore<T, CO_T>(zp, acc);
+      } else {
+        float lo[4] = {acc[0], acc[1], acc[2], acc[3]}, hi[4] = {acc[4], acc[5], acc[6], acc[7]};
+        vstore<T, 4>(zp, lo);
+        vstore<T, 4>(zp + 4, hi);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CO_T; j++)
+        if (co0 + j < Cout) zp[j] = from_f32<T>(acc[j]);
+    }
+  }
+  if (partials) {
+    block_sum<2 * CO_T>(st, red);
+    if (tid < 2 * CO_T) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * CO_T; i++) v = (tid == i) ? st[i] : v;
+      const int which = tid / CO_T, j = tid % CO_T;
+      if (co0 + j < Cout) partials[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + j] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// direct 3x3 weight gradient: grid (pixel blocks, Cout/CO_T, Cin); a thread walks pixels and
+// keeps 9 x CO_T accumulators for one input channel; each workgroup writes its 72 sums to a
+// row of partials [blk][Cout][Cin][9] that a second launch adds in a fixed order (no atomics:
+// bitwise reproducible).
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const T* __restrict__ x,
                                                                           const T* __restrict__ dz,
-                                                                          float* __restrict__ dw, int B, int H, int W,
-                                                                          int Cin, int Cout, int64_t pix_per_blk,
+                                                                          float* __restrict__ partials, int B, int H,
+                                                                          int W, int Cin, int Cout, int pix_per_blk,
                                                                           const float* __restrict__ x_aff) {
   __shared__ float red[9 * CO_T * (CD_THREADS / 64)];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int co0 = blockIdx.y * CO_T, ci = blockIdx.z;
-  const int64_t n_pix = (int64_t)B * H * W;
-  const int64_t p0 = (int64_t)blockIdx.x * pix_per_blk;
-  int64_t p1 = p0 + pix_per_blk;
+  const unsigned n_pix = (unsigned)B * H * W;
+  const unsigned p0 = blockIdx.x * (unsigned)pix_per_blk;
+  unsigned p1 = p0 + (unsigned)pix_per_blk;
   if (p1 > n_pix) p1 = n_pix;
   float acc[9][CO_T];
 #pragma unroll
@@ -163,26 +261,36 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
 #pragma unroll
     for (int j = 0; j < CO_T; j++) acc[t][j] = 0.f;
   const bool vec_dz = (Cout % CO_T == 0) && (sizeof(T) * CO_T == 16) && (((uintptr_t)dz & 15) == 0);
-  for (int64_t pix = p0 + tid; pix < p1; pix += CD_THREADS) {
-    const int px = (int)(pix % W), py = (int)((pix / W) % H);
+  float asc = 1.f, ash = 0.f;
+  if (x_aff) {
+    asc = x_aff[ci];
+    ash = x_aff[Cin + ci];
+  }
+  for (unsigned pix = p0 + tid; pix < p1; pix += CD_THREADS) {
+    const unsigned row = pix / (unsigned)W;
+    const int px = (int)(pix - row * (unsigned)W), py = (int)(row % (unsigned)H);
     float g[CO_T];
     if (vec_dz) {
-      vload<T, CO_T>(dz + pix * Cout + co0, g);
+      vload<T, CO_T>(dz + (int64_t)pix * Cout + co0, g);
     } else {
 #pragma unroll
-      for (int j = 0; j < CO_T; j++) g[j] = (co0 + j < Cout) ? to_f32(dz[pix * Cout + co0 + j]) : 0.f;
+      for (int j = 0; j < CO_T; j++) g[j] = (co0 + j < Cout) ? to_f32(dz[(int64_t)pix * Cout + co0 + j]) : 0.f;
     }
+    // all 9 taps are loaded first (clamped address, zero selected for the padding): the loads are
+    // in flight together instead of one latency per tap
+    float xv[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
       const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-      float xv = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        xv = to_f32(x[(pix + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * Cin + ci]);
-        if (x_aff) xv = to_f32(from_f32<T>(fmaxf(xv * x_aff[ci] + x_aff[Cin + ci], 0.f)));
-      }
-#pragma unroll
-      for (int j = 0; j < CO_T; j++) acc[t][j] += xv * g[j];
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      float v = to_f32(x[(ok ? (int64_t)pix + (t / 3 - 1) * W + (t % 3 - 1) : (int64_t)pix) * Cin + ci]);
+      if (x_aff) v = to_f32(from_f32<T>(fmaxf(v * asc + ash, 0.f)));
+      xv[t] = ok ? v : 0.f;
     }
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int j = 0; j < CO_T; j++) acc[t][j] += xv[t] * g[j];
   }
 #pragma unroll
   for (int t = 0; t < 9; t++)
@@ -196,7 +304,8 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
     float s = 0.f;
     for (int w = 0; w < CD_THREADS / 64; w++) s += red[w * 72 + tid];
     const int t = tid / CO_T, j = tid % CO_T;
-    if (co0 + j < Cout) atomicAdd(&dw[((int64_t)(co0 + j) * Cin + ci) * 9 + t], s);
+    if (co0 + j < Cout)
+      partials[(int64_t)blockIdx.x * 9 * Cin * Cout + ((int64_t)(co0 + j) * Cin + ci) * 9 + t] = s;
   }
 }
 
@@ -409,7 +518,17 @@ int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const
   if (gx > CD_MAX_BLOCKS) gx = CD_MAX_BLOCKS;
   dim3 grid(gx, cdiv(Cout, CO_T));
   float* partials = stats ? (float*)workspace : nullptr;
-  if (dtype == MIS_F32) {
+  if (Cin == 1 || Cin == 3) {
+#define FIRST_LAUNCH(TT, CIN)                                                                               \
+  conv3x3_first_kernel<TT, CIN><<<grid, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)wp, bias, (TT*)z, partials, B, \
+                                                             H, W, Cout, in_aff)
+    if (dtype == MIS_F32) {
+      if (Cin == 1) FIRST_LAUNCH(float, 1); else FIRST_LAUNCH(float, 3);
+    } else {
+      if (Cin == 1) FIRST_LAUNCH(bf16, 1); else FIRST_LAUNCH(bf16, 3);
+    }
+#undef FIRST_LAUNCH
+  } else if (dtype == MIS_F32) {
     if (Cin % 4 == 0 && ((uintptr_t)x % 16) == 0)
       conv3x3_direct_kernel<float, 4><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)wp, bias, (float*)z,
                                                                     partials, B, H, W, Cin, Cout, in_aff);
@@ -449,27 +568,43 @@ int conv3x3_direct_pack(const float* w, int Cw_out, int Cw_in, int transposed, i
   return MIS_OK;
 }
 
-int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
-                         int Cout, float* dw, hipStream_t st) {
-  const int64_t n_pix = (int64_t)B * H * W;
-  if (hipMemsetAsync(dw, 0, (size_t)Cout * Cin * 9 * sizeof(float), st) != hipSuccess) {
-    mis_set_error("conv3x3_wgrad: memset failed");
-    return MIS_ERR_LAUNCH;
-  }
+namespace {
+// pixel blocks of the direct weight gradient: enough workgroups to fill the chip across the
+// (Cout/CO_T, Cin) grid dimensions, at most 512 rows of partials
+int wgrad_direct_blocks(int64_t n_pix, int Cin, int Cout) {
   int nblk = (int)((n_pix + CD_THREADS * 16 - 1) / (CD_THREADS * 16));
   const int per = cdiv(Cout, CO_T) * Cin;
-  const int cap = per >= 2048 ? 1 : 2048 / per;
+  const int cap = per >= 1024 ? 1 : 1024 / per;
   if (nblk > cap) nblk = cap;
-  if (nblk < 1) nblk = 1;
-  const int64_t ppb = (n_pix + nblk - 1) / nblk;
+  if (nblk > 512) nblk = 512;
+  return nblk < 1 ? 1 : nblk;
+}
+}  // namespace
+
+size_t conv3x3_direct_wgrad_workspace_bytes(int64_t n_pix, int Cin, int Cout) {
+  return align256((size_t)wgrad_direct_blocks(n_pix, Cin, Cout) * 9 * Cin * Cout * sizeof(float));
+}
+
+int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
+                         int Cout, float* dw, void* workspace, hipStream_t st) {
+  const int64_t n_pix = (int64_t)B * H * W;
+  if (n_pix >= ((int64_t)1 << 31) || !workspace) {
+    mis_set_error("conv3x3_wgrad: needs a workspace and B*H*W < 2^31");
+    return MIS_ERR_ARG;
+  }
+  const int nblk = wgrad_direct_blocks(n_pix, Cin, Cout);
+  const int ppb = (int)((n_pix + nblk - 1) / nblk);
+  float* partials = (float*)workspace;
   dim3 grid(nblk, cdiv(Cout, CO_T), Cin);
   if (dtype == MIS_F32)
-    conv3x3_wgrad_direct_kernel<float><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)dz, dw, B, H, W, Cin,
-                                                                     Cout, ppb, x_aff);
+    conv3x3_wgrad_direct_kernel<float><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)dz, partials, B, H,
+                                                                     W, Cin, Cout, ppb, x_aff);
   else
-    conv3x3_wgrad_direct_kernel<bf16><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)dz, dw, B, H, W, Cin,
-                                                                    Cout, ppb, x_aff);
+    conv3x3_wgrad_direct_kernel<bf16><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)dz, partials, B, H, W,
+                                                                    Cin, Cout, ppb, x_aff);
   MIS_CHECK_LAUNCH("conv3x3_wgrad_direct_kernel");
+  launch_reduce_partials(partials, nblk, 9 * Cin * Cout, dw, st);
+  MIS_CHECK_LAUNCH("reduce_partials_kernel");
   return MIS_OK;
 }
 

@@ -11,8 +11,9 @@ int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout);
 // the kernel reads relu(x*scale + shift) instead of x (padding stays zero).
 int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
                        int W, int Cin, int Cout, void* z, float* stats, void* workspace, hipStream_t st);
+size_t conv3x3_direct_wgrad_workspace_bytes(int64_t n_pix, int Cin, int Cout);
 int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
-                         int Cout, float* dw, hipStream_t st);
+                         int Cout, float* dw, void* workspace, hipStream_t st);
 
 size_t conv3x3_direct_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_direct_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
