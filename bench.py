@@ -90,6 +90,7 @@ def main():
     from medical_image_segmentation_amd.utils.loss_fn import diceloss
     from medical_image_segmentation_amd.utils.metrics import Metrics
     from medical_image_segmentation_amd.parallel import GradSync
+    from medical_image_segmentation_amd.utils.optim import clip_and_step
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     names = ["a", "b", "c"]
@@ -118,8 +119,7 @@ def main():
         ld["total_loss"].backward()
         if sync is not None:
             sync.finish_step()
-        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
-        opt.step()
+        clip_and_step(opt, params, max_norm=1.0)      # clip_grad_norm_ + AdamW.step (train_and_eval.py:115-118)
         return ld
 
     def barrier():

@@ -232,6 +232,39 @@ int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dt
 /* channels-last activations inside).                                           */
 int mis_nchw_f32_to_nhwc(const float* x, int B, int C, int H, int W, int dtype, void* y, mis_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) followed by                  */
+/* torch.optim.AdamW.step() (utils/train_and_eval.py:115-118, train.py:221-226)  */
+/* over all parameter tensors in two launches.  descs: device array of           */
+/* mis_param_desc, one per tensor (float32, dense).  Work is cut into chunks of   */
+/* MIS_OPT_CHUNK elements: chunk_prefix (device int[n_tensors+1]) holds each      */
+/* tensor's first chunk, chunk_prefix[n_tensors] = n_chunks.                      */
+/* mis_grad_sqsum writes one partial per chunk into the workspace;                */
+/* mis_clip_adamw_step then (for the chunks [chunk_begin, chunk_end) — one call   */
+/* per optimizer param group, each with its own hyper-parameters) forms           */
+/* total_norm = sqrt(sum of partials) (written to total_norm[0] if not NULL, by   */
+/* the call whose range contains chunk 0), clip = min(1, max_norm/(norm+1e-6))    */
+/* (max_norm <= 0: no clipping), g *= clip, and applies the AdamW update with     */
+/* bias corrections for `step` (1-based) exactly as torch's non-fused AdamW:      */
+/* p *= 1-lr*wd; m = lerp(m,g,1-b1); v = b2*v+(1-b2)*g*g;                          */
+/* p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).                            */
+/* write_clipped_grads != 0 stores the clipped gradients back (as torch does).    */
+#define MIS_OPT_CHUNK 4096
+typedef struct {
+  float* p;        /* parameter            */
+  float* g;        /* gradient             */
+  float* m;        /* exp_avg              */
+  float* v;        /* exp_avg_sq           */
+  int64_t n;       /* elements             */
+} mis_param_desc;
+size_t mis_clip_adamw_workspace_bytes(int n_chunks);
+int mis_grad_sqsum(const void* descs, const int* chunk_prefix, int n_tensors, int n_chunks, void* workspace,
+                   mis_stream_t stream);
+int mis_clip_adamw_step(const void* descs, const int* chunk_prefix, int n_tensors, int chunk_begin, int chunk_end,
+                        int n_chunks, const void* workspace, float max_norm, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, int64_t step, int write_clipped_grads, float* total_norm,
+                        mis_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MISAMD_LIBRARY") or os.path.join(_HERE, "libmisamd.so
 
 F32, BF16 = 0, 1
 
-_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/misamd.h one to one
 PROTOTYPES = {
@@ -41,6 +41,9 @@ PROTOTYPES = {
     "mis_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mis_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_clip_adamw_workspace_bytes": (_sz, [_i]),
+    "mis_grad_sqsum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "mis_clip_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _d, _d, _d, _d, _d, _i64, _i, _vp, _vp]),
     "mis_conv3x3_cat_supported": (_i, [_i] * 7),
     "mis_conv3x3_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_split_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,117 @@
+"""clip_grad_norm_ + AdamW.step() in two kernel launches.
+
+The reference's step is `torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)` followed by
+`optimizer.step()` on a torch.optim.AdamW (utils/train_and_eval.py:115-118, train.py:221-226).
+`clip_and_step` does the same arithmetic on the optimizer's own state tensors (`exp_avg`,
+`exp_avg_sq`, `step`), so the optimizer object, its `state_dict()` and checkpoints stay
+interchangeable with torch's.  Anything it does not recognise — another optimizer class,
+amsgrad/maximize/capturable, sparse or non-float32 tensors, an enabled GradScaler — runs
+torch's own `clip_grad_norm_` + `optimizer.step()` unchanged.
+"""
+import torch
+
+from .. import functional as F_
+from .._lib import call, query
+
+CHUNK = 4096          # MIS_OPT_CHUNK in include/misamd.h
+
+
+class _Plan:
+    """Device table of (param, grad, exp_avg, exp_avg_sq, n) rows and the chunk prefix; rebuilt
+    only when a pointer changed (gradients are usually re-allocated at the same addresses)."""
+
+    def __init__(self):
+        self.key = None
+        self.descs = self.prefix = None
+        self.n_chunks = 0
+        self.group_chunks = []
+
+
+_PLANS = {}
+
+
+def _fusable(optimizer, params):
+    if type(optimizer) is not torch.optim.AdamW:
+        return False
+    listed = set()
+    for g in optimizer.param_groups:
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            return False
+        if isinstance(g["lr"], torch.Tensor):
+            return False
+        for p in g["params"]:
+            if p.grad is None:
+                continue
+            if (not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse
+                    or not p.is_contiguous() or not p.grad.is_contiguous()):
+                return False
+            listed.add(id(p))
+    # the clip norm must be taken over exactly the tensors being stepped
+    clip = {id(p) for p in params if p.grad is not None}
+    return clip == listed and len(listed) > 0
+
+
+def clip_and_step(optimizer, params, max_norm=1.0):
+    """clip_grad_norm_(params, max_norm) + optimizer.step().  Returns the total gradient norm (a
+    0-dim tensor), like clip_grad_norm_."""
+    params = [p for p in params]
+    if not _fusable(optimizer, params):
+        norm = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+        optimizer.step()
+        return norm
+    groups, steps = [], []
+    for g in optimizer.param_groups:
+        ps = [p for p in g["params"] if p.grad is not None]
+        if not ps:
+            continue
+        st = None
+        for p in ps:
+            s = optimizer.state[p]
+            if len(s) == 0:                 # same lazy initialisation as torch.optim.AdamW
+                s["step"] = torch.tensor(0.0, dtype=torch.float32)
+                s["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            k = float(s["step"])
+            if st is None:
+                st = k
+            elif k != st:                   # per-tensor step counts differ: leave it to torch
+                norm = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+                optimizer.step()
+                return norm
+        groups.append((g, ps))
+        steps.append(int(st) + 1)
+    dev = groups[0][1][0].device
+    rows = []
+    for g, ps in groups:
+        for p in ps:
+            s = optimizer.state[p]
+            rows.append((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), p.numel()))
+    plan = _PLANS.setdefault(id(optimizer), _Plan())
+    key = tuple(rows)
+    if plan.key != key:
+        prefix, c = [], 0
+        plan.group_chunks = []
+        for g, ps in groups:
+            c0 = c
+            for p in ps:
+                prefix.append(c)
+                c += (p.numel() + CHUNK - 1) // CHUNK
+            plan.group_chunks.append((c0, c))
+        prefix.append(c)
+        plan.n_chunks = c
+        plan.descs = torch.tensor(rows, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+        plan.prefix = torch.tensor(prefix, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+        plan.key = key
+    st = torch.cuda.current_stream().cuda_stream
+    ws = F_.workspace(query("mis_clip_adamw_workspace_bytes", plan.n_chunks), dev)
+    norm = torch.empty((), dtype=torch.float32, device=dev)
+    n_t = len(rows)
+    call("mis_grad_sqsum", plan.descs.data_ptr(), plan.prefix.data_ptr(), n_t, plan.n_chunks, ws.data_ptr(), st)
+    for (g, ps), (c0, c1), step in zip(groups, plan.group_chunks, steps):
+        b1, b2 = g["betas"]
+        call("mis_clip_adamw_step", plan.descs.data_ptr(), plan.prefix.data_ptr(), n_t, c0, c1, plan.n_chunks,
+             ws.data_ptr(), float(max_norm), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+             float(g["weight_decay"]), step, 1, norm.data_ptr() if c0 == 0 else None, st)
+        for p in ps:
+            optimizer.state[p]["step"] += 1
+    return norm

@@ -11,7 +11,9 @@ Differences that do not change results:
     (the reference synchronises 7*(n+1) times per batch through .item());
   * per-batch losses are accumulated detached (the reference keeps graph-attached tensors);
   * with a GradSync (data parallel) attached to the model, gradients are averaged across
-    ranks before unscale/clip, overlapped with the backward pass.
+    ranks before unscale/clip, overlapped with the backward pass;
+  * gradient clipping and the AdamW update run as two fused launches on the optimizer's own
+    state (utils/optim.py); other optimizers, or an enabled GradScaler, use torch's calls.
 """
 import numpy as np
 import torch
@@ -22,6 +24,9 @@ try:
 except ImportError:          # progress bar only
     def tqdm(it, **kw):
         return it
+
+
+from .optim import clip_and_step
 
 
 def _grad_sync(model):
@@ -78,12 +83,11 @@ def train_one_epoch(model, optimizer, epoch, train_dataloader, device, loss_fn, 
             sync.finish_step()
         if use_scaler:
             scaler.unscale_(optimizer)
-        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
-        if use_scaler:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
             scaler.step(optimizer)
             scaler.update()
         else:
-            optimizer.step()
+            clip_and_step(optimizer, params, max_norm=1.0)     # clip_grad_norm_ + optimizer.step(), two launches
         scheduler.step()
         vals = torch.stack([l.detach().float() for l in losses])
         epoch_losses = vals if epoch_losses is None else epoch_losses + vals

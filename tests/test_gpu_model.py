@@ -187,3 +187,41 @@ def test_checkpoint_roundtrip_with_reference_keys(tmp_path):
     assert len(sd) == 128
     m2 = build(c, torch.float32)
     m2.load_state_dict(sd)
+
+
+def test_fused_clip_adamw_matches_torch():
+    """utils.optim.clip_and_step against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step on
+    identical clones (two param groups, 3 steps, norms above and below the clip threshold), and the
+    optimizer state stays loadable by a plain torch AdamW."""
+    from medical_image_segmentation_amd.utils.optim import clip_and_step
+    shapes = [(8, 1, 3, 3), (8,), (32, 8, 3, 3), (32,), (5000,), (4097,), (1,), (64, 64, 3, 3)]
+    mk = lambda: [torch.nn.Parameter(T(dg.hash_normalish(s, 1200 + i, std=0.3)).to(DEV)) for i, s in enumerate(shapes)]
+    pa, pb = mk(), mk()
+    groups = lambda ps: [{"params": ps[:5], "lr": 8e-4, "weight_decay": 1e-4},
+                         {"params": ps[5:], "lr": 3e-3, "weight_decay": 0.0, "betas": (0.9, 0.99)}]
+    oa = torch.optim.AdamW(groups(pa), betas=(0.95, 0.999), eps=1e-8)
+    ob = torch.optim.AdamW(groups(pb), betas=(0.95, 0.999), eps=1e-8)
+    for step, gscale in enumerate([5.0, 1e-3, 0.7]):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = T(dg.hash_normalish(shapes[i], 1300 + 10 * step + i, std=gscale)).to(DEV)
+            a.grad, b.grad = g.clone(), g.clone()
+        na = clip_and_step(oa, pa, max_norm=1.0)
+        nb = torch.nn.utils.clip_grad_norm_(pb, max_norm=1.0)
+        ob.step()
+        assert abs(float(na) - float(nb)) <= 2e-6 * float(nb)
+        for a, b in zip(pa, pb):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-8
+            assert float((a.grad - b.grad).abs().max()) <= 2e-6 * float(b.grad.abs().max()) + 1e-12
+            sa, sb = oa.state[a], ob.state[b]
+            assert float(sa["step"]) == float(sb["step"]) == step + 1
+            assert rel_err(sa["exp_avg"], sb["exp_avg"]) < 2e-6 and rel_err(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 2e-6
+    oc = torch.optim.AdamW(groups(mk()), betas=(0.95, 0.999), eps=1e-8)
+    oc.load_state_dict(oa.state_dict())          # same state layout as torch's own
+    # an optimizer the fused path does not take runs torch's calls unchanged
+    ps = mk()
+    sgd = torch.optim.SGD(ps, lr=0.1)
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    before = [p.detach().clone() for p in ps]
+    clip_and_step(sgd, ps, max_norm=1.0)
+    assert all(float((b - p).abs().max()) > 0 for b, p in zip(before, ps))
