@@ -52,8 +52,11 @@ inline int grid_for_fixed_channels(int want, int CV, int cap) {
   return grid < g ? g : grid;
 }
 
-// stats: [rows][2][C] partial (sum, sum of squares); rows == 1 is the reduced form.  32 row
-// lanes x 32 channels per workgroup, double accumulation, fixed order (bitwise reproducible).
+// stats: [rows][2][C] partial (sum, sum of squares); rows == 1 is the reduced form.  A workgroup
+// of 1024 threads owns CL channels (8/16/32: fewer channels -> more row lanes, so narrow layers
+// still spread their rows over the whole workgroup); 4 independent loads in flight per thread,
+// double accumulation, fixed-order tree (bitwise reproducible).
+template <int CL>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int rows, int C,
                                                            double inv_n, double unbias,
                                                            const float* __restrict__ gamma,
@@ -62,27 +65,41 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                            float* __restrict__ scale_shift,
                                                            float* __restrict__ mean_rstd) {
-  __shared__ double red[2][32][33];
-  const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  constexpr int RL = 1024 / CL;
+  __shared__ double red[2][RL][CL + 1];
+  const int cl = threadIdx.x % CL, r = threadIdx.x / CL;
+  const int c = blockIdx.x * CL + cl;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int i = r; i < rows; i += 32) {
-      s1 += (double)stats[(int64_t)i * 2 * C + c];
-      s2 += (double)stats[(int64_t)i * 2 * C + C + c];
+    const int64_t st = 2 * (int64_t)C;
+    int i = r;
+    for (; i + 3 * RL < rows; i += 4 * RL) {
+      const float a0 = stats[i * st + c], a1 = stats[(i + RL) * st + c];
+      const float a2 = stats[(i + 2 * RL) * st + c], a3 = stats[(i + 3 * RL) * st + c];
+      const float b0 = stats[i * st + C + c], b1 = stats[(i + RL) * st + C + c];
+      const float b2 = stats[(i + 2 * RL) * st + C + c], b3 = stats[(i + 3 * RL) * st + C + c];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; i < rows; i += RL) {
+      s1 += (double)stats[i * st + c];
+      s2 += (double)stats[i * st + C + c];
     }
   }
   red[0][r][cl] = s1;
   red[1][r][cl] = s2;
   __syncthreads();
-  if (r != 0 || c >= C) return;
-  s1 = s2 = 0.0;
-#pragma unroll
-  for (int k = 0; k < 32; k++) {
-    s1 += red[0][k][cl];
-    s2 += red[1][k][cl];
+  for (int h = RL / 2; h >= 1; h >>= 1) {
+    if (r < h) {
+      red[0][r][cl] += red[0][r + h][cl];
+      red[1][r][cl] += red[1][r + h][cl];
+    }
+    __syncthreads();
   }
+  if (r != 0 || c >= C) return;
+  s1 = red[0][0][cl];
+  s2 = red[1][0][cl];
   // the conv kernels hand over float32 sums; keep the reduced sums' float32 rounding so that the
   // one-row and the many-row forms give identical results
   const double mean = (double)(float)s1 * inv_n;
@@ -314,10 +331,15 @@ int mis_bn_finalize(const float* stats, int stats_rows, int C, int64_t n, const 
   MIS_REQUIRE(C >= 1 && n >= 1 && stats_rows >= 1, "bn_finalize: bad shape C=%d n=%lld rows=%d", C, (long long)n,
               stats_rows);
   const double unbias = n > 1 ? (double)n / (double)(n - 1) : 1.0;
-  bn_finalize_kernel<<<cdiv(C, 32), 1024, 0, (hipStream_t)stream>>>(stats, stats_rows, C, 1.0 / (double)n, unbias,
-                                                                    gamma, beta, eps, momentum, running_mean,
-                                                                    running_var, num_batches_tracked, scale_shift,
-                                                                    mean_rstd);
+#define FIN_LAUNCH(CL)                                                                                       \
+  bn_finalize_kernel<CL><<<cdiv(C, CL), 1024, 0, (hipStream_t)stream>>>(stats, stats_rows, C, 1.0 / (double)n, unbias, \
+                                                                        gamma, beta, eps, momentum, running_mean,   \
+                                                                        running_var, num_batches_tracked,           \
+                                                                        scale_shift, mean_rstd)
+  if (C <= 64) FIN_LAUNCH(8);
+  else if (C <= 256) FIN_LAUNCH(16);
+  else FIN_LAUNCH(32);
+#undef FIN_LAUNCH
   MIS_CHECK_LAUNCH("bn_finalize_kernel");
   return MIS_OK;
 }
