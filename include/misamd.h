@@ -102,8 +102,14 @@ int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, i
 /* alias dx) is a second gradient of x — the encoder output also feeds the       */
 /* decoder as a skip connection (model/unet.py:67,72,77,81) — summed in here      */
 /* (autograd's accumulation of the two uses, without a separate pass).           */
+/* bn_sums (nullable): x is the lazy output of conv+BatchNorm(train)+ReLU and      */
+/* x_affine is [4][C] (scale, shift, mean, rstd); the kernel then also produces    */
+/* float32 [2][C] = (sum dy, sum dy*xhat) with dy = dx where the activation is     */
+/* positive — exactly what mis_bn_relu_bwd_reduce would compute from (x, dx) in a   */
+/* separate pass (needs the workspace of mis_maxpool2x2_bwd_workspace_bytes).       */
+size_t mis_maxpool2x2_bwd_workspace_bytes(int C);
 int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, const void* dx_add, int dtype, int B,
-                       int H, int W, int C, void* dx, mis_stream_t stream);
+                       int H, int W, int C, void* dx, float* bn_sums, void* workspace, mis_stream_t stream);
 /* out[b][2h][2w][0:Cup] = bilinear(low), out[...][Cup:Cup+Cskip] = skip.        */
 int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const void* skip, const float* skip_affine,
                            int dtype, int B, int h, int w, int Cup, int Cskip, void* out, mis_stream_t stream);
@@ -223,8 +229,11 @@ int mis_conv1x1_fwd(const void* x, const float* x_affine, int dtype, int64_t n_p
                     const float* w, const float* bias, void* y, mis_stream_t stream);
 size_t mis_conv1x1_bwd_workspace_bytes(int64_t n_pix, int Cin, int Cout);
 /* dx (same dtype), dw float32 [Cout][Cin], dbias float32 [Cout]; dx may be NULL. */
+/* bn_sums (nullable): as for mis_maxpool2x2_bwd — x_affine is then [4][Cin] and   */
+/* float32 [2][Cin] = (sum dy, sum dy*xhat) over (x, dx) is produced in the same    */
+/* pass (dx must be requested).                                                    */
 int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int64_t n_pix, int Cin,
-                    int Cout, const float* w, void* dx, float* dw, float* dbias, void* workspace,
+                    int Cout, const float* w, void* dx, float* dw, float* dbias, float* bn_sums, void* workspace,
                     mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */

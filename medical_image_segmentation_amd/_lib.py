@@ -29,7 +29,8 @@ PROTOTYPES = {
     "mis_dice_from_sums": (_i, [_vp, _i, _f, _vp, _vp]),
     "mis_loss_bwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "mis_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_maxpool2x2_bwd_workspace_bytes": (_sz, [_i]),
+    "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_upsample2x_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_upsample2x_cat_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mis_conv3x3_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
@@ -58,7 +59,7 @@ PROTOTYPES = {
     "mis_channel_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "mis_conv1x1_fwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv1x1_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
-    "mis_conv1x1_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_conv1x1_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_nchw_f32_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 

@@ -38,19 +38,37 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
   }
 }
 
+__global__ __launch_bounds__(1024) void reduce_partials3_kernel(const float* __restrict__ partials, int nblk, int n,
+                                                                int n0, int n1, float* __restrict__ out0,
+                                                                float* __restrict__ out1, float* __restrict__ out2) {
+  __shared__ double red[32][33];
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
+  double s = 0.0;
+  if (j < n) {
+    int i = r;
+    for (; i + 96 < nblk; i += 128) {
+      const float a0 = partials[(int64_t)i * n + j], a1 = partials[(int64_t)(i + 32) * n + j];
+      const float a2 = partials[(int64_t)(i + 64) * n + j], a3 = partials[(int64_t)(i + 96) * n + j];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; i < nblk; i += 32) s += (double)partials[(int64_t)i * n + j];
+  }
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0 && j < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) t += red[k][c];
+    if (j < n0) out0[j] = (float)t;
+    else if (j < n0 + n1) out1[j - n0] = (float)t;
+    else out2[j - n0 - n1] = (float)t;
+  }
+}
+
 namespace {
 
 constexpr int EW_THREADS = 256;
-
-// Largest grid <= min(want, cap) such that grid*256 is a multiple of CV (so that a grid-stride
-// thread keeps one channel vector); at least the smallest such grid.
-inline int grid_for_fixed_channels(int want, int CV, int cap) {
-  int g = 1;
-  while (((int64_t)g * EW_THREADS) % CV != 0) g++;
-  if (want > cap) want = cap;
-  int grid = (want / g) * g;
-  return grid < g ? g : grid;
-}
 
 // stats: [rows][2][C] partial (sum, sum of squares); rows == 1 is the reduced form.  A workgroup
 // of 1024 threads owns CL channels (8/16/32: fewer channels -> more row lanes, so narrow layers

@@ -355,8 +355,12 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
                                                                  const float* __restrict__ w, T* __restrict__ dx,
                                                                  float* __restrict__ partials, int64_t n_pix, int Cin,
                                                                  int64_t pix_per_blk,
-                                                                 const float* __restrict__ x_aff) {
-  extern __shared__ float red[];                 // [256][CO*V + CO]
+                                                                 const float* __restrict__ x_aff, int bn) {
+  // bn != 0: x is the lazy output of conv+BatchNorm(train)+ReLU and x_aff is [4][Cin] (scale,
+  // shift, mean, rstd): the sums that BatchNorm's backward needs over (z, dx) — sum(dy) and
+  // sum(dy*xhat), dy = dx where the activation is positive — are accumulated here, where both
+  // are in registers, and appended to the partial row (2*Cin values).
+  extern __shared__ float red[];                 // [256][CO*V + CO], reused as [256][2V] for the BatchNorm sums
   constexpr int NR = CO * V + CO;
   const int tid = threadIdx.x;
   const int CV = Cin / V, PR = CD_THREADS / CV;
@@ -373,6 +377,13 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
     asc[k] = x_aff ? x_aff[c0 + k] : 1.f;
     ash[k] = x_aff ? x_aff[Cin + c0 + k] : 0.f;
   }
+  float bmean[V], brstd[V], bs[2][V];
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    bmean[k] = bn ? x_aff[2 * Cin + c0 + k] : 0.f;
+    brstd[k] = bn ? x_aff[3 * Cin + c0 + k] : 0.f;
+    bs[0][k] = bs[1][k] = 0.f;
+  }
   float aw[CO][V], ab[CO];
 #pragma unroll
   for (int j = 0; j < CO; j++) {
@@ -384,9 +395,11 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
   int64_t p1 = p0 + pix_per_blk;
   if (p1 > n_pix) p1 = n_pix;
   for (int64_t p = p0 + pr; pr < PR && p < p1; p += PR) {
-    float g[CO], xv[V], d[V];
+    float g[CO], xv[V], d[V], zr[V];
     vload<T, CO>(dy + p * CO, g);
     vload<T, V>(x + p * Cin + c0, xv);
+#pragma unroll
+    for (int k = 0; k < V; k++) zr[k] = xv[k];
     if (x_aff) {
 #pragma unroll
       for (int k = 0; k < V; k++) xv[k] = fmaxf(xv[k] * asc[k] + ash[k], 0.f);
@@ -403,6 +416,14 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
       }
     }
     if (dx) vstore<T, V>(dx + p * Cin + c0, d);
+    if (bn) {
+#pragma unroll
+      for (int k = 0; k < V; k++) {
+        const float dd = (xv[k] > 0.f) ? to_f32(from_f32<T>(d[k])) : 0.f;     // the value the next pass would read
+        bs[0][k] += dd;
+        bs[1][k] += dd * ((zr[k] - bmean[k]) * brstd[k]);
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < CO; j++) {
@@ -411,7 +432,8 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
     red[tid * NR + CO * V + j] = ab[j];
   }
   __syncthreads();
-  float* prow = partials + (int64_t)blockIdx.x * (CO * Cin + CO);
+  const int row_n = CO * Cin + CO + (bn ? 2 * Cin : 0);
+  float* prow = partials + (int64_t)blockIdx.x * row_n;
   for (int o = tid; o < CO * Cin + CO; o += CD_THREADS) {
     float acc = 0.f;
     if (o < CO * Cin) {
@@ -422,6 +444,20 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
       for (int r = 0; r < PR; r++) acc += red[(r * CV) * NR + CO * V + j];     // cv == 0 lanes
     }
     prow[o] = acc;
+  }
+  if (bn) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int k = 0; k < V; k++) red[(tid * 2 + q) * V + k] = bs[q][k];
+    __syncthreads();
+    for (int e = tid; e < 2 * Cin; e += CD_THREADS) {
+      const int q = e / Cin, c = e % Cin, ocv = c / V, k = c % V;
+      float acc = 0.f;
+      for (int r = 0; r < PR; r++) acc += red[((r * CV + ocv) * 2 + q) * V + k];
+      prow[CO * Cin + CO + e] = acc;
+    }
   }
 }
 
@@ -451,7 +487,7 @@ int conv1x1_fwd_t(const void* x, const float* x_aff, int64_t n_pix, int Cin, con
 
 template <typename T, int CO>
 int conv1x1_bwd_t(const void* x, const float* x_aff, const void* dy, int64_t n_pix, int Cin, const float* w, void* dx,
-                  float* dw, float* dbias, void* ws, hipStream_t st) {
+                  float* dw, float* dbias, float* bn_sums, void* ws, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const bool vec = pick_vec<T>(Cin, x, dx) == N && (CD_THREADS % (Cin / N)) == 0;
   const int V = vec ? N : 1;
@@ -461,17 +497,18 @@ int conv1x1_bwd_t(const void* x, const float* x_aff, const void* dy, int64_t n_p
   if (nblk < 1) nblk = 1;
   const int64_t ppb = (n_pix + nblk - 1) / nblk;
   float* partials = (float*)ws;
-  const size_t lds = (size_t)CD_THREADS * (CO * V + CO) * sizeof(float);
+  const size_t lds = (size_t)CD_THREADS * (CO * V + CO > 2 * V ? CO * V + CO : 2 * V) * sizeof(float);
+  const int bn = bn_sums ? 1 : 0;
   if (vec) {
     auto k = conv1x1_bwd_kernel<T, N, CO>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k<<<nblk, CD_THREADS, lds, st>>>((const T*)x, (const T*)dy, w, (T*)dx, partials, n_pix, Cin, ppb, x_aff);
+    k<<<nblk, CD_THREADS, lds, st>>>((const T*)x, (const T*)dy, w, (T*)dx, partials, n_pix, Cin, ppb, x_aff, bn);
   } else {
     conv1x1_bwd_kernel<T, 1, CO><<<nblk, CD_THREADS, lds, st>>>((const T*)x, (const T*)dy, w, (T*)dx, partials, n_pix,
-                                                                 Cin, ppb, x_aff);
+                                                                 Cin, ppb, x_aff, bn);
   }
-  launch_reduce_partials(partials, nblk, CO * Cin, dw, st, CO * Cin + CO);
-  launch_reduce_partials(partials + CO * Cin, nblk, CO, dbias, st, CO * Cin + CO);
+  // one launch sums the partial rows into dw, dbias and (optionally) the BatchNorm sums
+  launch_reduce_partials3(partials, nblk, CO * Cin + CO + (bn ? 2 * Cin : 0), CO * Cin, CO, dw, dbias, bn_sums, st);
   return 0;
 }
 
@@ -624,16 +661,18 @@ int mis_conv1x1_fwd(const void* x, const float* x_affine, int dtype, int64_t n_p
 }
 
 size_t mis_conv1x1_bwd_workspace_bytes(int64_t n_pix, int Cin, int Cout) {
-  return align256((size_t)C1_MAX_BLOCKS * ((size_t)Cout * Cin + Cout) * sizeof(float));
+  return align256((size_t)C1_MAX_BLOCKS * ((size_t)Cout * Cin + Cout + 2 * (size_t)Cin) * sizeof(float));
 }
 
 int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int64_t n_pix, int Cin, int Cout,
-                    const float* w, void* dx, float* dw, float* dbias, void* workspace, mis_stream_t stream) {
+                    const float* w, void* dx, float* dw, float* dbias, float* bn_sums, void* workspace,
+                    mis_stream_t stream) {
+  MIS_REQUIRE(!bn_sums || (x_affine && dx), "conv1x1_bwd: bn_sums needs the [4][Cin] affine and dx");
   MIS_REQUIRE(x && dy && w && dw && dbias && workspace && n_pix >= 1 && Cin >= 1, "conv1x1_bwd: bad arguments");
   MIS_REQUIRE(Cout >= 1 && Cout <= 16, "conv1x1_bwd: 1 <= Cout <= 16 required (got %d)", Cout);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MIS_F32) { DISPATCH_CO(conv1x1_bwd_t, float, Cout, x, x_affine, dy, n_pix, Cin, w, dx, dw, dbias, workspace, st) }
-  else if (dtype == MIS_BF16) { DISPATCH_CO(conv1x1_bwd_t, bf16, Cout, x, x_affine, dy, n_pix, Cin, w, dx, dw, dbias, workspace, st) }
+  if (dtype == MIS_F32) { DISPATCH_CO(conv1x1_bwd_t, float, Cout, x, x_affine, dy, n_pix, Cin, w, dx, dw, dbias, bn_sums, workspace, st) }
+  else if (dtype == MIS_BF16) { DISPATCH_CO(conv1x1_bwd_t, bf16, Cout, x, x_affine, dy, n_pix, Cin, w, dx, dw, dbias, bn_sums, workspace, st) }
   else MIS_REQUIRE(false, "conv1x1_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("conv1x1_bwd_kernel");
   return MIS_OK;

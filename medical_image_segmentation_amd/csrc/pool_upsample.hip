@@ -10,10 +10,12 @@
 //   up+cat bwd : read 4*n_low*(Cup+Cskip), write n_low*Cup + 4*n_low*Cskip
 #include "common.h"
 #include "vec.h"
+#include "reduce.h"
 
 namespace {
 
 constexpr int EW_THREADS = 256;
+constexpr int POOL_MAX_ROWS = 4096;      // partial rows (= workgroups) of the pooling backward's fused sums
 
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
@@ -57,11 +59,20 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __rest
   }
 }
 
+// Backward of the pooling (+ optional second gradient `add` of the same tensor).  When the
+// pooled tensor is a lazy activation whose producer is conv+BatchNorm(train)+ReLU, the very
+// next step of the backward pass is that BatchNorm's reduction over (z, dx):
+//     sum(dy), sum(dy * xhat)  with  dy = dx where the activation is positive, xhat = (z-mean)*rstd.
+// Both z and dx are in registers here, so with `bn_partials` the kernel accumulates these sums
+// too (per-thread, fixed channel vector; fixed-order block reduction; one partial row
+// [2][C] per workgroup) and that layer's separate reduction pass over 2 tensors disappears.
+// `in_aff` is then [4][C]: scale, shift, mean, rstd.
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  const T* add, T* dx, int B, int H, int W, int C,
-                                                                 const float* __restrict__ in_aff) {
-  extern __shared__ float aff_lds[];
+                                                                 const float* __restrict__ in_aff,
+                                                                 float* __restrict__ bn_partials) {
+  extern __shared__ float aff_lds[];          // [2][C] affine table, reused as [256][2V] reduction scratch
   const float* aff = nullptr;
   if (in_aff) {
     for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) aff_lds[i] = in_aff[i];
@@ -70,7 +81,18 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __rest
   }
   const int Ho = H >> 1, Wo = W >> 1, CV = C / V;
   const int64_t total = (int64_t)B * Ho * Wo * CV;
-  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+  const int64_t i0 = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  float bmean[V], brstd[V], bs[2][V];
+  if (bn_partials) {
+    const int c0 = (int)(i0 % CV) * V;        // fixed for this thread (the grid is sized for that)
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      bmean[k] = in_aff[2 * C + c0 + k];
+      brstd[k] = in_aff[3 * C + c0 + k];
+      bs[0][k] = bs[1][k] = 0.f;
+    }
+  }
+  for (int64_t i = i0; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
     const int cv = (int)(i % CV);
     int64_t p = i / CV;
     const int xo = (int)(p % Wo);
@@ -79,13 +101,17 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __rest
     const int b = (int)(p / Ho);
     const int64_t off = (((int64_t)b * H + 2 * yo) * W + 2 * xo) * C + cv * V;
     const T* src = x + off;
-    float v[4][V], g[V], o[4][V];
-    vload<T, V>(src, v[0]);
-    vload<T, V>(src + C, v[1]);
-    vload<T, V>(src + (int64_t)W * C, v[2]);
-    vload<T, V>(src + (int64_t)W * C + C, v[3]);
+    float zr[4][V], v[4][V], g[V], o[4][V];
+    vload<T, V>(src, zr[0]);
+    vload<T, V>(src + C, zr[1]);
+    vload<T, V>(src + (int64_t)W * C, zr[2]);
+    vload<T, V>(src + (int64_t)W * C + C, zr[3]);
 #pragma unroll
-    for (int j = 0; j < 4; j++) affine_relu<V>(v[j], aff, C, cv * V);
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int k = 0; k < V; k++) v[j][k] = zr[j][k];
+      affine_relu<V>(v[j], aff, C, cv * V);
+    }
     vload<T, V>(dy + i * V, g);
 #pragma unroll
     for (int k = 0; k < V; k++) {
@@ -114,11 +140,38 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __rest
 #pragma unroll
         for (int k = 0; k < V; k++) o[j][k] += a4[j][k];
     }
+    if (bn_partials) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          const float d = (v[j][k] > 0.f) ? to_f32(from_f32<T>(o[j][k])) : 0.f;   // the value the next pass would read
+          bs[0][k] += d;
+          bs[1][k] += d * ((zr[j][k] - bmean[k]) * brstd[k]);
+        }
+    }
     T* dst = dx + off;
     vstore<T, V>(dst, o[0]);
     vstore<T, V>(dst + C, o[1]);
     vstore<T, V>(dst + (int64_t)W * C, o[2]);
     vstore<T, V>(dst + (int64_t)W * C + C, o[3]);
+  }
+  if (bn_partials) {
+    // fixed-order block reduction: thread t holds channel vector (blockIdx*256 + t) % CV
+    __syncthreads();
+    float* red = aff_lds;                      // [256][2V]
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int k = 0; k < V; k++) red[(threadIdx.x * 2 + q) * V + k] = bs[q][k];
+    __syncthreads();
+    const int base = (int)(((int64_t)blockIdx.x * EW_THREADS) % CV);
+    for (int j = threadIdx.x; j < 2 * C; j += EW_THREADS) {
+      const int q = j / C, c = j % C, cv = c / V, k = c % V;
+      float acc = 0.f;
+      for (int t = (cv - base + CV) % CV; t < EW_THREADS; t += CV) acc += red[(t * 2 + q) * V + k];
+      bn_partials[(int64_t)blockIdx.x * 2 * C + j] = acc;
+    }
   }
 }
 
@@ -413,16 +466,32 @@ int pool_fwd(const void* x, void* y, int B, int H, int W, int C, const float* af
 
 template <typename T>
 int pool_bwd(const void* x, const void* dy, const void* add, void* dx, int B, int H, int W, int C, const float* aff,
-             hipStream_t st) {
+             float* bn_sums, void* ws, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
-  const size_t lds = aff ? 2 * (size_t)C * sizeof(float) : 0;
-  if (pick_vec<T>(C, x, dy, dx, add) == N)
-    maxpool_bwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>(
-        (const T*)x, (const T*)dy, (const T*)add, (T*)dx, B, H, W, C, aff);
+  const bool vec = pick_vec<T>(C, x, dy, dx, add) == N;
+  const int V = vec ? N : 1;
+  size_t lds = aff ? 2 * (size_t)C * sizeof(float) : 0;
+  int grid = ew_grid(n / V, EW_THREADS);
+  float* partials = nullptr;
+  if (bn_sums) {
+    // fixed channel vector per thread; one partial row per workgroup
+    // few enough partial rows that the final reduction (rows x 2C floats) stays small
+    int cap = 32768 / C;
+    if (cap < 256) cap = 256;
+    if (cap > POOL_MAX_ROWS) cap = POOL_MAX_ROWS;
+    grid = grid_for_fixed_channels(grid, C / V, cap);
+    const size_t red = (size_t)EW_THREADS * 2 * V * sizeof(float);
+    if (red > lds) lds = red;
+    partials = (float*)ws;
+  }
+  if (vec)
+    maxpool_bwd_kernel<T, N><<<grid, EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)add, (T*)dx, B, H, W,
+                                                             C, aff, partials);
   else
-    maxpool_bwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>(
-        (const T*)x, (const T*)dy, (const T*)add, (T*)dx, B, H, W, C, aff);
+    maxpool_bwd_kernel<T, 1><<<grid, EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)add, (T*)dx, B, H, W,
+                                                             C, aff, partials);
+  if (bn_sums) launch_reduce_partials(partials, grid, 2 * C, bn_sums, st);
   return 0;
 }
 
@@ -517,14 +586,19 @@ int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, i
   return MIS_OK;
 }
 
+size_t mis_maxpool2x2_bwd_workspace_bytes(int C) {
+  return C < 1 ? 0 : align256((size_t)POOL_MAX_ROWS * 2 * C * sizeof(float));
+}
+
 int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, const void* dx_add, int dtype, int B,
-                       int H, int W, int C, void* dx, mis_stream_t stream) {
+                       int H, int W, int C, void* dx, float* bn_sums, void* workspace, mis_stream_t stream) {
   MIS_REQUIRE(x && dy && dx, "maxpool2x2_bwd: null pointer");
+  MIS_REQUIRE(!bn_sums || (x_affine && workspace), "maxpool2x2_bwd: bn_sums needs the [4][C] affine and a workspace");
   MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
               "maxpool2x2_bwd: H and W must be even and >= 2 (got %dx%d)", H, W);
   MIS_REQUIRE(C <= 4096, "maxpool2x2_bwd: C too large");
-  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx_add, dx, B, H, W, C, x_affine, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx_add, dx, B, H, W, C, x_affine, (hipStream_t)stream);
+  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx_add, dx, B, H, W, C, x_affine, bn_sums, workspace, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx_add, dx, B, H, W, C, x_affine, bn_sums, workspace, (hipStream_t)stream);
   else MIS_REQUIRE(false, "maxpool2x2_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("maxpool_bwd_kernel");
   return MIS_OK;

@@ -40,6 +40,26 @@ static inline void launch_reduce_partials(const float* partials, int nblk, int n
   reduce_partials_kernel<<<cdiv(n, 32), 1024, 0, st>>>(partials, nblk, n, stride ? stride : n, out);
 }
 
+// Same reduction with the n outputs split over up to three destinations (n0, n1, rest).
+__global__ void reduce_partials3_kernel(const float* __restrict__ partials, int nblk, int n, int n0, int n1,
+                                        float* __restrict__ out0, float* __restrict__ out1,
+                                        float* __restrict__ out2);
+
+static inline void launch_reduce_partials3(const float* partials, int nblk, int n, int n0, int n1, float* out0,
+                                           float* out1, float* out2, hipStream_t st) {
+  reduce_partials3_kernel<<<cdiv(n, 32), 1024, 0, st>>>(partials, nblk, n, n0, n1, out0, out1, out2);
+}
+
+// Largest grid <= min(want, cap) such that grid*256 is a multiple of CV (so that a grid-stride
+// thread of a 256-thread block keeps one channel vector); at least the smallest such grid.
+static inline int grid_for_fixed_channels(int want, int CV, int cap) {
+  int g = 1;
+  while (((int64_t)g * 256) % CV != 0) g++;
+  if (want > cap) want = cap;
+  int grid = (want / g) * g;
+  return grid < g ? g : grid;
+}
+
 // F provides:  static constexpr int NOUT;
 //              __device__ void prepare(int c0)          (per-thread channel constants -> registers)
 //              __device__ void load(int64_t pix, int c0, float (&acc)[NOUT][V]) const   (accumulates)

@@ -231,6 +231,37 @@ def channel_sum_raw(x):
 # ---------------------------------------------------------------------------
 # Conv3x3 + BatchNorm2d + ReLU   (model/utils/modules.py:86-94)
 # ---------------------------------------------------------------------------
+FUSE_BN_SUMS = True      # producers of `da` that hold z in registers also emit the BatchNorm-backward sums
+
+
+def attach_bn_sums(da, sums, z):
+    """Tags the gradient tensor `da` (gradient with respect to the activation of the lazy tensor
+    z) with the BatchNorm-backward sums computed alongside it.  The tag only reaches the
+    producing layer's backward if autograd hands the very same tensor object through, i.e. if
+    nothing was accumulated into or derived from it — exactly when the sums are still valid."""
+    da._mis_bn_sums = (sums, z.data_ptr(), z._version, da.data_ptr())
+    return da
+
+
+def take_bn_sums(da, z):
+    tag = getattr(da, "_mis_bn_sums", None)
+    if tag is None:
+        return None
+    sums, zp, zv, dp = tag
+    if zp != z.data_ptr() or zv != z._version or dp != da.data_ptr():
+        return None
+    return sums
+
+
+BN_SUMS_MIN_NUMEL = 50_000_000   # below this the layer's own small reduction pass is as cheap (measured crossover
+                              # on MI355X is ~5e7 elements; tests lower it to exercise the path)
+
+
+def _wants_bn_sums(x_ss, numel):
+    return (FUSE_BN_SUMS and x_ss is not None and x_ss.dim() == 2 and x_ss.shape[0] == 4
+            and numel >= BN_SUMS_MIN_NUMEL)
+
+
 class ConvBnReluFn(torch.autograd.Function):
     """(x, x_ss) -> (z, ss): the activation relu(bn(conv(act(x)))) in LAZY form — the conv output z
     plus the BatchNorm affine ss = [scale, shift]; consumers apply relu(z*scale + shift) when they
@@ -260,8 +291,10 @@ class ConvBnReluFn(torch.autograd.Function):
             wf, ctx.wt = pack_weights(weight.detach(), x.dtype), None
         z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout,
                                "partial" if training else False, x_ss, x2, x2_ss)
-        ss = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
-        mr = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+        # the lazy handle: rows (scale, shift) are what consumers apply; rows (mean, rstd) ride along
+        # for the backward pass (this layer's, possibly fused into the consumer's backward kernel)
+        ss = torch.empty((4, Cout), dtype=torch.float32, device=x.device)
+        mr = ss[2:]
         st = _stream()
         if training:
             if n_pix <= 1:
@@ -274,7 +307,7 @@ class ConvBnReluFn(torch.autograd.Function):
                  beta.data_ptr(), Cout, eps, ss.data_ptr(), st)
             mr[0].copy_(running_mean)
             mr[1].copy_(torch.rsqrt(running_var + eps))
-        ctx.save_for_backward(x, x_ss, x2, x2_ss, z, weight, gamma, beta, mr)
+        ctx.save_for_backward(x, x_ss, x2, x2_ss, z, weight, gamma, beta, ss)
         ctx.training = training
         ctx.has_bias = bias is not None
         ctx.mark_non_differentiable(ss)
@@ -284,17 +317,22 @@ class ConvBnReluFn(torch.autograd.Function):
     def backward(ctx, da, _dss):
         if da is None:
             return (None,) * 14
-        x, x_ss, x2, x2_ss, z, weight, gamma, beta, mr = ctx.saved_tensors
+        x, x_ss, x2, x2_ss, z, weight, gamma, beta, ss = ctx.saved_tensors
+        mr = ss[2:]
         B, Ca, H, W = x.shape
         Cout, Cin = weight.shape[0], weight.shape[1]
         n_pix = B * H * W
-        da = to_act(da, x.dtype)
         st = _stream()
-        sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+        # (sum dy, sum dy*xhat): already produced by the kernel that wrote `da` when that kernel had
+        # both z and da in registers (max-pool backward, 1x1-conv backward), else one pass over (z, da)
+        sums = take_bn_sums(da, z)
+        da = to_act(da, x.dtype)
         ws = workspace(query("mis_bn_relu_bwd_workspace_bytes", n_pix, Cout), x.device)
-        with _prof("bn_relu_bwd_reduce", 0, 2 * z.numel() * z.element_size()):
-            call("mis_bn_relu_bwd_reduce", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
-                 gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ws.data_ptr(), st)
+        if sums is None:
+            sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+            with _prof("bn_relu_bwd_reduce", 0, 2 * z.numel() * z.element_size()):
+                call("mis_bn_relu_bwd_reduce", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
+                     gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ws.data_ptr(), st)
         dgamma, dbeta = sums[1], sums[0]          # rows of one buffer; nothing below writes it
         # eval mode: statistics are constants, so the two projection terms vanish
         proj = sums if ctx.training else torch.zeros_like(sums)
@@ -367,10 +405,14 @@ def _maxpool_bwd(x, x_ss, dy, dx_add=None):
         dx_add = to_act(dx_add, x.dtype)
     dx = torch.empty_like(x)
     nbytes = (2 * x.numel() + dy.numel() + (x.numel() if dx_add is not None else 0)) * x.element_size()
+    sums = ws = None
+    if _wants_bn_sums(x_ss, x.numel()):
+        sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+        ws = workspace(query("mis_maxpool2x2_bwd_workspace_bytes", Cc), x.device)
     with _prof("maxpool2x2_bwd", 0, nbytes):
         call("mis_maxpool2x2_bwd", x.data_ptr(), _p(x_ss), dy.data_ptr(), _p(dx_add), _dt(x), B, H, W, Cc,
-             dx.data_ptr(), _stream())
-    return dx
+             dx.data_ptr(), _p(sums), _p(ws), _stream())
+    return attach_bn_sums(dx, sums, x) if sums is not None else dx
 
 
 class MaxPool2x2Fn(torch.autograd.Function):
@@ -490,9 +532,14 @@ class Conv1x1Fn(torch.autograd.Function):
         dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
         ws = workspace(query("mis_conv1x1_bwd_workspace_bytes", B * H * W, Cin, Cout), x.device)
+        sums = None
+        if dx is not None and _wants_bn_sums(x_ss, x.numel()):
+            sums = torch.empty((2, Cin), dtype=torch.float32, device=x.device)
         with _prof("conv1x1_bwd", 4 * B * H * W * Cin * Cout, (2 * x.numel() + dy.numel()) * x.element_size()):
             call("mis_conv1x1_bwd", x.data_ptr(), _p(x_ss), dy.data_ptr(), _dt(x), B * H * W, Cin, Cout,
-                 weight.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream())
+                 weight.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(), _p(sums), ws.data_ptr(), _stream())
+        if sums is not None:
+            attach_bn_sums(dx, sums, x)
         return dx, None, dw, (db if ctx.has_bias else None)
 
 

@@ -364,7 +364,7 @@ def test_conv_bn_relu(F_, dtype, shape, lazy):
         conv.weight.copy_(T(w)); conv.bias.copy_(T(b)); bn.weight.copy_(T(gam)); bn.bias.copy_(T(bet))
     xd = act(x, dtype).requires_grad_(True)
     z, ss = F_.conv_bn_relu(xd, ss_in.to(DEV) if lazy else None, conv, bn, True)
-    assert ss.shape == (2, Co) and not ss.requires_grad
+    assert ss.shape == (4, Co) and not ss.requires_grad      # scale, shift | mean, rstd
     a = F_.materialize(z, ss)
     a.backward(act(gy, dtype))
     ao, grads, mean, var = _cbr_oracle(x, w, b, gam, bet, gy, dtype, x_value)
@@ -609,3 +609,54 @@ def test_double_conv_two_inputs_matches_concat(F_):
     assert rel_err(xbd.grad, vb.grad) < 1e-5      # gradient with respect to the skip's VALUE
     for a, b_ in zip(g2, [p.grad for p in m.parameters()]):
         assert rel_err(a, b_) < 1e-5
+
+
+# ---------------------------------------------------------------------------
+# BatchNorm-backward sums produced by the kernel that writes the gradient
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("consumer", ["pool", "conv1x1"])
+def test_bn_sums_fused_into_gradient_producer(F_, dtype, consumer):
+    """conv+BN+ReLU followed by max-pool(+skip) or the 1x1 head: with the fusion on, the consumer's
+    backward kernel emits (sum dy, sum dy*xhat) and the layer's own reduction pass is skipped; every
+    gradient must equal the unfused run's (same arithmetic, different summation order)."""
+    B, Ci, Co, H, W = 2, 8, 16, 16, 32
+    x = np.maximum(dg.hash_normalish((B, Ci, H, W), 1401), 0)
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm2d(Co).to(DEV)
+    head = torch.nn.Conv2d(Co, 4, 1).to(DEV)
+    gy = dg.hash_normalish((B, Co, H // 2, W // 2), 1402)
+    gs = dg.hash_normalish((B, Co, H, W), 1403, std=0.3)
+    gl = dg.hash_normalish((B, 4, H, W), 1404)
+    res, calls = [], []
+    orig = F_.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+
+    min_numel = F_.BN_SUMS_MIN_NUMEL
+    for fuse in (True, False):
+        F_.FUSE_BN_SUMS = fuse
+        F_.BN_SUMS_MIN_NUMEL = 0          # the production threshold only selects large tensors
+        F_.call = spy
+        calls.clear()
+        try:
+            for m in (conv, bn, head):
+                m.zero_grad()
+            xd = act(x, dtype).requires_grad_(True)
+            z, ss = F_.conv_bn_relu(xd, None, conv, bn, True)
+            if consumer == "pool":
+                y, skip = F_.PoolSkipFn.apply(z, ss)
+                torch.autograd.backward([y, skip], [act(gy, dtype), act(gs, dtype)])
+            else:
+                F_.Conv1x1Fn.apply(z, ss, head.weight, head.bias).backward(act(gl, dtype))
+        finally:
+            F_.call = orig
+            F_.FUSE_BN_SUMS = True
+            F_.BN_SUMS_MIN_NUMEL = min_numel
+        assert ("mis_bn_relu_bwd_reduce" in calls) == (not fuse)
+        res.append([xd.grad.float().clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()])
+    tol = 2e-5 if dtype == torch.float32 else 2e-3
+    for a, b in zip(*res):
+        assert rel_err(a, b) < tol

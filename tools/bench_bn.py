@@ -60,8 +60,11 @@ def main():
         dx = torch.empty_like(x)
         add = torch.randn_like(x)
         tf = timeit(lambda: call("mis_maxpool2x2_fwd", x.data_ptr(), ss.data_ptr(), 1, B, hw, hw, C, y.data_ptr(), st))
-        tb = timeit(lambda: call("mis_maxpool2x2_bwd", x.data_ptr(), ss.data_ptr(), y.data_ptr(), add.data_ptr(), 1, B,
-                                 hw, hw, C, dx.data_ptr(), st))
+        ss4 = torch.rand(4, C, device=dev)
+        sums = torch.empty(2, C, device=dev)
+        wsp = F_.workspace(query("mis_maxpool2x2_bwd_workspace_bytes", C), dev)
+        tb = timeit(lambda: call("mis_maxpool2x2_bwd", x.data_ptr(), ss4.data_ptr(), y.data_ptr(), add.data_ptr(), 1, B,
+                                 hw, hw, C, dx.data_ptr(), sums.data_ptr(), wsp.data_ptr(), st))
         mb = x.numel() * 2 / 1e6
         print(f"{name:8s} {C:4d} {hw:4d} {mb:6.1f} | fwd {tf:7.1f} us {1.25 * mb / tf:5.2f} TB/s | bwd(+add) {tb:7.1f} us {3.25 * mb / tb:5.2f} TB/s")
     for name, C, h in [("up1", 256, 32), ("up2", 128, 64), ("up3", 64, 128), ("up4", 32, 256)]:
