@@ -141,7 +141,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    loss_val = float(ld["total_loss"])
+    loss_val = float(ld["total_loss"].detach())
     # host post-math of the metrics for the timed steps (outside the timed region: the counts
     # were produced inside it)
     from medical_image_segmentation_amd.utils.train_and_eval import _finish_metrics
