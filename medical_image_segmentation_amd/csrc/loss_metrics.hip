@@ -180,28 +180,32 @@ __global__ __launch_bounds__(LM_THREADS) void loss_metrics_kernel(
 }
 
 // Fixed-order reduction of the per-block partials; T_c comes from the integer counts.
-__global__ void loss_sums_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
-                                          const unsigned long long* __restrict__ cm, int B,
-                                          float* __restrict__ sums) {
-  __shared__ double red[256];
+// 1024 threads: value v = tid % VP (VP = 2C rounded up to a power of two) is summed by
+// 1024/VP row lanes (double accumulators), then a tree over the lanes in LDS.
+__global__ __launch_bounds__(1024) void loss_sums_finalize_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                                  const unsigned long long* __restrict__ cm, int B,
+                                                                  float* __restrict__ sums) {
+  __shared__ double red[1024];
   const int tid = threadIdx.x;
-  for (int v = 0; v < 2 * C; v++) {
-    double s = 0.0;
-    for (int i = tid; i < nblk; i += 256) s += (double)partials[(int64_t)i * 2 * C + v];
-    red[tid] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
-    }
-    if (tid == 0) sums[v] = (float)red[0];
+  int VP = 1;
+  while (VP < 2 * C) VP <<= 1;
+  const int v = tid % VP, r = tid / VP, RL = 1024 / VP;
+  double s = 0.0;
+  if (v < 2 * C)
+    for (int i = r; i < nblk; i += RL) s += (double)partials[(int64_t)i * 2 * C + v];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = RL / 2; o > 0; o >>= 1) {
+    if (r < o) red[tid] += red[tid + o * VP];
     __syncthreads();
   }
-  if (tid < C) {
+  if (tid < 2 * C) sums[tid] = (float)red[tid];
+  if (tid >= 64 && tid < 64 + C) {
+    const int c = tid - 64;
     unsigned long long t = 0;
     for (int b = 0; b < B; b++)
-      for (int p = 0; p < C; p++) t += cm[((int64_t)b * C + tid) * C + p];
-    sums[2 * C + tid] = (float)t;
+      for (int p = 0; p < C; p++) t += cm[((int64_t)b * C + c) * C + p];
+    sums[2 * C + c] = (float)t;
   }
 }
 
@@ -359,7 +363,7 @@ int mis_loss_metrics_fwd(const void* logits, int dtype, int64_t sb, int64_t sc, 
   }
   MIS_CHECK_LAUNCH("loss_metrics_kernel");
   if (sums) {
-    loss_sums_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, C, cmw, B, sums);
+    loss_sums_finalize_kernel<<<1, 1024, 0, st>>>(partials, nblk, C, cmw, B, sums);
     MIS_CHECK_LAUNCH("loss_sums_finalize_kernel");
   }
   return MIS_OK;
