@@ -242,6 +242,33 @@ int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dt
 int mis_nchw_f32_to_nhwc(const float* x, int B, int C, int H, int W, int dtype, void* y, mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
+/* Sliding-window prediction — utils/slide_predict.py:60-117.                    */
+/*                                                                               */
+/* mis_slide_gather_tiles: crops n_tiles windows out of a uint8 [H][W][C] image  */
+/* (tile_yx int32 [n_tiles][2] device = top-left corners) into a channels-last   */
+/* activation [n_tiles][window][window][C] of value u8/255 — the                 */
+/* `from_numpy(crop).permute(2,0,1).float()/255.0` of slide_predict.py:83-87.    */
+int mis_slide_gather_tiles(const uint8_t* image, int H, int W, int C, const int32_t* tile_yx, int n_tiles,
+                           int window, int dtype, void* out, mis_stream_t stream);
+/* mis_argmax_classes: `torch.argmax(pred, dim=1)` (slide_predict.py:92) as      */
+/* uint8 [B][HW]; first maximal class, NaN maximal.  logits element (b,c,p) at   */
+/* b*stride_b + c*stride_c + p*stride_p.  1 <= C <= 256.                         */
+int mis_argmax_classes(const void* logits, int dtype, int64_t stride_b, int64_t stride_c, int64_t stride_p, int B,
+                       int C, int HW, uint8_t* out, mis_stream_t stream);
+/* mis_slide_blend: the Gaussian-weighted accumulation, normalisation and        */
+/* rounding of slide_predict.py:74-112.  Tile k = i*nx + j (the reference's      */
+/* order, duplicates of the clamped last row/column included) has its top-left   */
+/* corner at (ys[i], xs[j]) and its uint8 class map at                           */
+/* class_maps[map_index[k]] ([window][window]); gauss = float64 [window][window] */
+/* weights.  Per output pixel the covering tiles are visited in tile order with  */
+/* float32 accumulators updated in float64, as numpy evaluates                   */
+/* `out[...] += mask * weight`; out uint8 [out_h][out_w] (the unpadded image).   */
+/* ny + nx <= 4096.                                                              */
+int mis_slide_blend(const uint8_t* class_maps, const int32_t* map_index, const int32_t* ys, const int32_t* xs,
+                    int ny, int nx, int window, const double* gauss, int out_h, int out_w, uint8_t* out,
+                    mis_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) followed by                  */
 /* torch.optim.AdamW.step() (utils/train_and_eval.py:115-118, train.py:221-226)  */
 /* over all parameter tensors in two launches.  descs: device array of           */

@@ -61,6 +61,9 @@ PROTOTYPES = {
     "mis_conv1x1_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
     "mis_conv1x1_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_nchw_f32_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_slide_gather_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "mis_argmax_classes": (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp, _vp]),
+    "mis_slide_blend": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
 }
 
 _lib = None

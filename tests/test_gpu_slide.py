@@ -1,0 +1,158 @@
+"""GPU suite: the sliding-window predictor (tile gather, per-pixel class, ordered blend)
+through the C-ABI against the oracle and the golden class maps the reference itself wrote.
+
+Everything here is integer/byte output: the comparisons are bit-exact, except the run with a
+real U-Net, where a float32 near-tie between two class logits may legitimately resolve
+differently on CPU and GPU (agreement >= 99.5 % of the pixels is required there).
+"""
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from oracle import datagen as dg
+from oracle import unet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def sp():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU suite needs a HIP device")
+    from medical_image_segmentation_amd import _lib
+    _lib.load()
+    from medical_image_segmentation_amd.utils import slide_predict
+    return slide_predict
+
+
+def call(name, *args):
+    from medical_image_segmentation_amd._lib import call as c
+    c(name, *args)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def int_class_of(img, ncls):
+    """Class of a pixel as an exact integer function of its RGB bytes (CPU side)."""
+    v = img.astype(np.int64)
+    return ((v[..., 0] * 3 + v[..., 1] * 5 + v[..., 2] * 7) // 11) % ncls
+
+
+class IntClassModel(torch.nn.Module):
+    """The same function on the device from the [0,1] floats the predictor feeds a model:
+    x*255 rounds back to the byte exactly, so CPU and GPU class maps are identical."""
+
+    def __init__(self, ncls):
+        super().__init__()
+        self.ncls = ncls
+
+    def forward(self, x):
+        v = torch.round(x.float() * 255.0).to(torch.int64)
+        cls = torch.div(v[:, 0] * 3 + v[:, 1] * 5 + v[:, 2] * 7, 11, rounding_mode="floor") % self.ncls
+        return torch.nn.functional.one_hot(cls, self.ncls).permute(0, 3, 1, 2).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_tiles(sp, dtype):
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (70, 90, 3), generator=g, dtype=torch.uint8)
+    corners = [(0, 0), (38, 58), (5, 17), (38, 0)]
+    ws = 32
+    d = img.to(DEV)
+    yx = torch.tensor(corners, dtype=torch.int32, device=DEV)
+    out = torch.empty((len(corners), 3, ws, ws), dtype=dtype, device=DEV, memory_format=torch.channels_last)
+    call("mis_slide_gather_tiles", d.data_ptr(), 70, 90, 3, yx.data_ptr(), len(corners), ws,
+         0 if dtype == torch.float32 else 1, out.data_ptr(), stream())
+    for k, (y, x) in enumerate(corners):
+        ref = (img[y:y + ws, x:x + ws].permute(2, 0, 1).float() / 255.0).to(dtype)
+        assert torch.equal(out[k].cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_argmax_classes(sp, dtype, layout):
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W = 3, 5, 9, 13
+    x = torch.randint(-3, 4, (B, C, H, W), generator=g).float()      # many exact ties
+    x[0, 2, 1, 1] = float("nan")
+    x[1, :, 0, 0] = float("nan")
+    x = x.to(dtype).to(DEV)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    sb, sc, sh, sw = x.stride()
+    out = torch.empty((B, H * W), dtype=torch.uint8, device=DEV)
+    call("mis_argmax_classes", x.data_ptr(), 0 if dtype == torch.float32 else 1, sb, sc, sw, B, C, H * W,
+         out.data_ptr(), stream())
+    ref = torch.argmax(x.float().cpu(), dim=1).reshape(B, -1)
+    assert torch.equal(out.cpu().long(), ref)
+
+
+def test_slide_matches_reference_golden(sp, golden):
+    """The reference's own predict() output for a per-pixel stub model (fixture slide.npz)."""
+    g = golden("slide")
+    model = mg.StubSegModel().to(DEV)
+    for name, c in mg.slide_cases().items():
+        img = (dg.hash_u64((c["h"], c["w"], 3), c["seed"]) % np.uint64(256)).astype(np.uint8)
+        pred = sp.SlidingWindowPredictor(model, DEV, c["window"], c["stride"])
+        res = pred.predict_array(img)
+        assert res.dtype == np.uint8 and res.shape == (c["h"], c["w"])
+        assert np.array_equal(res, g[f"{name}.result"]), name
+
+
+@pytest.mark.parametrize("h,w,ws,st,batch", [(300, 500, 64, 32, None), (257, 131, 32, 8, 5), (512, 512, 128, 64, 3),
+                                             (96, 96, 96, 96, None), (1000, 1100, 256, 128, None)])
+def test_slide_exact_against_oracle(sp, h, w, ws, st, batch):
+    """Bit-exact against the oracle's tile-by-tile float32 accumulation, duplicates included,
+    for window/stride ratios 1 to 4 and ragged sizes."""
+    ncls = 6
+    g = np.random.default_rng(h * 7 + w)
+    img = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    pred = sp.SlidingWindowPredictor(IntClassModel(ncls), DEV, ws, st)
+    pred.batch_tiles = batch
+    res = pred.predict_array(img)
+    padded, _ = orc.slide_pad(img, ws, st)
+    pos = orc.slide_positions(padded.shape[0], padded.shape[1], ws, st)
+    assert pos == pred._split_image(padded)
+    maps = [int_class_of(padded[y0:y1, x0:x1], ncls) for (y0, y1, x0, x1) in pos]
+    ref = orc.slide_blend(maps, pos, padded.shape[:2], (h, w), ws)
+    assert np.array_equal(res, ref)
+
+
+def test_slide_predict_files(sp, tmp_path):
+    from PIL import Image
+    img = (dg.hash_u64((40, 56, 3), 92) % np.uint64(256)).astype(np.uint8)
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    Image.fromarray(img).save(src)
+    pred = sp.SlidingWindowPredictor(IntClassModel(4), DEV, 16, 8)
+    pred.predict(src, dst)
+    assert np.array_equal(np.array(Image.open(dst)), pred.predict_array(img))
+
+
+def test_slide_with_unet(sp):
+    """End to end with the HIP U-Net in eval mode against the oracle's U-Net on the CPU."""
+    from medical_image_segmentation_amd.model.unet import UNet
+    st = orc.make_state(3, 4, base=8, seed=31)
+    model = UNet(3, 4, 0, base_channels=8).to(DEV)
+    model.load_state_dict(st)
+    model.eval()
+    g = np.random.default_rng(9)
+    # smooth image: class regions instead of per-pixel noise
+    base = g.integers(0, 256, (9, 11, 3)).astype(np.float32)
+    img = torch.nn.functional.interpolate(torch.from_numpy(base).permute(2, 0, 1)[None], size=(70, 90),
+                                          mode="bilinear")[0].permute(1, 2, 0).round().clamp(0, 255).byte().numpy()
+    ws, stride = 32, 16
+    pred = sp.SlidingWindowPredictor(model, DEV, ws, stride)
+    res = pred.predict_array(img)
+    padded, _ = orc.slide_pad(img, ws, stride)
+    pos = orc.slide_positions(padded.shape[0], padded.shape[1], ws, stride)
+    maps = []
+    with torch.no_grad():
+        for (y0, y1, x0, x1) in pos:
+            tile = torch.from_numpy(padded[y0:y1, x0:x1]).permute(2, 0, 1).float()[None] / 255.0
+            maps.append(torch.argmax(orc.unet_forward(tile, st, training=False), dim=1)[0].numpy())
+    ref = orc.slide_blend(maps, pos, padded.shape[:2], img.shape[:2], ws)
+    assert (res == ref).mean() >= 0.995
