@@ -71,6 +71,26 @@ def cpu_baseline(size, threads):
             "phase_ms_per_step": {k: round(1e3 * v / n, 1) for k, v in timers.items()}}
 
 
+def pmc_traffic(roof, B, S, dtype):
+    """`traffic` of the roofline object: HBM bytes per kernel launch of the dominant family from
+    the L2 memory-side counters (2*FETCH_SIZE + WRITE_SIZE), collected over this same command by
+    tools/pmc_bench.sh in separate rocprofv3 --pmc runs and stored under profiles/.  Only valid
+    for the workload it was collected on (the default one)."""
+    import glob
+    if not roof or (B, S, dtype) != (16, 512, "bf16"):
+        return
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return
+    try:
+        fam = json.load(open(files[-1]))["families"].get(roof["kernel"])
+    except (OSError, ValueError, KeyError):
+        return
+    if fam:
+        roof["traffic"] = fam["traffic_bytes_per_kernel_launch"]
+        roof["traffic_unit"] = "bytes per kernel launch (PMC, %s)" % os.path.basename(files[-1])
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -155,6 +175,7 @@ def main():
         torch.cuda.synchronize()
         roof = F_.profile_summary(PEAK_HBM_GBS, PEAK_BF16_TFLOPS, steps=3)
         F_.PROFILE = None
+        pmc_traffic(roof["dominant"], B, S, args.dtype)
 
     if rank == 0:
         out = {

@@ -120,7 +120,9 @@ def profile_summary(peak_hbm_gbs, peak_tflops, steps=1):
         roof = {"bound": "hbm", "achieved": d["GBps"], "peak": peak_hbm_gbs, "unit": "GB/s",
                 "frac": round(d["GBps"] / peak_hbm_gbs, 4)}
     roof.update({"kernel": dom, "avg_launch_ms": round(d["ms_per_step"] / max(d["launches_per_step"], 1), 4),
-                 "launches_per_step": d["launches_per_step"], "traffic": None})
+                 "launches_per_step": d["launches_per_step"],
+                 "algorithmic_bytes_per_launch": d["alg_bytes_per_step"] // max(d["launches_per_step"], 1),
+                 "traffic": None})
     return {"dominant": roof, "kernels": fams}
 
 
