@@ -95,8 +95,15 @@ int mis_loss_bwd(const void* logits, int dtype, int64_t stride_b, int64_t stride
 /* Down / Up: nn.MaxPool2d(2,2) (model/unet.py:19,48,52,56,60) and             */
 /* nn.Upsample(2,'bilinear',align_corners=True) + torch.cat([up, skip], 1)      */
 /* (model/unet.py:20,66-67,71-72,76-77,80-81).  Channels-last, H and W even.    */
-int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, int H, int W, int C, void* y,
-                       mis_stream_t stream);
+/*                                                                              */
+/* nn.Dropout2d (model/unet.py:27-42; applied to every pooled tensor and to the  */
+/* center / decoder1 / decoder2 outputs, unet.py:49-74) is folded into these     */
+/* kernels: `noise` / `low_noise` (nullable) is its float32 [B][C] multiplier     */
+/* per (sample, channel) — 0 or 1/(1-p), drawn by the caller — applied to the     */
+/* pooled output (and to dy on the way back), respectively to the low-resolution  */
+/* activation before interpolation (and to dlow on the way back).                 */
+int mis_maxpool2x2_fwd(const void* x, const float* x_affine, const float* noise, int dtype, int B, int H, int W, int C,
+                       void* y, mis_stream_t stream);
 /* dx = gradient routed to the first maximum of each window (row-major scan,    */
 /* strict '>'), zero elsewhere; x is the forward input.  dx_add (nullable, may    */
 /* alias dx) is a second gradient of x — the encoder output also feeds the       */
@@ -108,13 +115,15 @@ int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, i
 /* positive — exactly what mis_bn_relu_bwd_reduce would compute from (x, dx) in a   */
 /* separate pass (needs the workspace of mis_maxpool2x2_bwd_workspace_bytes).       */
 size_t mis_maxpool2x2_bwd_workspace_bytes(int C);
-int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, const void* dx_add, int dtype, int B,
-                       int H, int W, int C, void* dx, float* bn_sums, void* workspace, mis_stream_t stream);
+int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const float* noise, const void* dy, const void* dx_add,
+                       int dtype, int B, int H, int W, int C, void* dx, float* bn_sums, void* workspace,
+                       mis_stream_t stream);
 /* out[b][2h][2w][0:Cup] = bilinear(low), out[...][Cup:Cup+Cskip] = skip.        */
-int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const void* skip, const float* skip_affine,
-                           int dtype, int B, int h, int w, int Cup, int Cskip, void* out, mis_stream_t stream);
+int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const float* low_noise, const void* skip,
+                           const float* skip_affine, int dtype, int B, int h, int w, int Cup, int Cskip, void* out,
+                           mis_stream_t stream);
 /* dlow[b][h][w][Cup] gathered from dout[..., 0:Cup]; dskip = dout[..., Cup:].   */
-int mis_upsample2x_cat_bwd(const void* dout, int dtype, int B, int h, int w, int Cup, int Cskip,
+int mis_upsample2x_cat_bwd(const void* dout, const float* low_noise, int dtype, int B, int h, int w, int Cup, int Cskip,
                            void* dlow, void* dskip, mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */

@@ -28,11 +28,11 @@ PROTOTYPES = {
     "mis_loss_metrics_fwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_dice_from_sums": (_i, [_vp, _i, _f, _vp, _vp]),
     "mis_loss_bwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
-    "mis_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_maxpool2x2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_maxpool2x2_bwd_workspace_bytes": (_sz, [_i]),
-    "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "mis_upsample2x_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mis_upsample2x_cat_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mis_upsample2x_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_upsample2x_cat_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mis_conv3x3_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mis_pack_conv3x3_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mis_set_conv_path": (_i, [_i]),

@@ -20,7 +20,8 @@ constexpr int POOL_MAX_ROWS = 4096;      // partial rows (= workgroups) of the p
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                  int B, int H, int W, int C,
-                                                                 const float* __restrict__ in_aff) {
+                                                                 const float* __restrict__ in_aff,
+                                                                 const float* __restrict__ noise) {
   extern __shared__ float aff_lds[];
   const float* aff = nullptr;
   if (in_aff) {
@@ -55,6 +56,10 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(const T* __rest
       mm = (v11[k] > mm || v11[k] != v11[k]) ? v11[k] : mm;
       m[k] = mm;
     }
+    if (noise) {      // Dropout2d on the pooled tensor: one multiplier per (sample, channel)
+#pragma unroll
+      for (int k = 0; k < V; k++) m[k] = to_f32(from_f32<T>(m[k])) * noise[(int64_t)b * C + cv * V + k];
+    }
     vstore<T, V>(y + i * V, m);
   }
 }
@@ -71,6 +76,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  const T* add, T* dx, int B, int H, int W, int C,
                                                                  const float* __restrict__ in_aff,
+                                                                 const float* __restrict__ noise,
                                                                  float* __restrict__ bn_partials) {
   extern __shared__ float aff_lds[];          // [2][C] affine table, reused as [256][2V] reduction scratch
   const float* aff = nullptr;
@@ -113,6 +119,10 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __rest
       affine_relu<V>(v[j], aff, C, cv * V);
     }
     vload<T, V>(dy + i * V, g);
+    if (noise) {      // gradient through the Dropout2d that followed the pooling
+#pragma unroll
+      for (int k = 0; k < V; k++) g[k] = to_f32(from_f32<T>(g[k] * noise[(int64_t)b * C + cv * V + k]));
+    }
 #pragma unroll
     for (int k = 0; k < V; k++) {
       float mm = v[0][k];
@@ -198,7 +208,8 @@ template <typename T, int CC>
 __global__ __launch_bounds__(EW_THREADS) void up_fwd_tiled_kernel(const T* __restrict__ low, T* __restrict__ out,
                                                                   int B, int h, int w, int C, int Cdst, float sy,
                                                                   float sx, int tiles_x, int tiles_y,
-                                                                  const float* __restrict__ low_aff) {
+                                                                  const float* __restrict__ low_aff,
+                                                                  const float* __restrict__ noise) {
   constexpr int G = 16 / (int)sizeof(T);        // channels per 16-byte vector
   constexpr int VC = CC / G;                    // vectors per pixel in this chunk
   constexpr int PITCH = VC * 16 + 16;           // LDS bytes per staged pixel (padded: odd number of 16-byte slots)
@@ -230,6 +241,10 @@ __global__ __launch_bounds__(EW_THREADS) void up_fwd_tiled_kernel(const T* __res
       float v[G];
       vload<T, G>(src + ((int64_t)gy * w + gx) * C + ch, v);
       affine_relu<G>(v, low_aff ? affl : nullptr, CC, cv * G);
+      if (noise) {    // Dropout2d between the producer and the upsampling
+#pragma unroll
+        for (int k = 0; k < G; k++) v[k] = to_f32(from_f32<T>(v[k])) * noise[(int64_t)b * C + ch + k];
+      }
       vstore<T, G>(reinterpret_cast<T*>(tile + pos * PITCH + cv * 16), v);
     }
   }
@@ -273,7 +288,8 @@ constexpr int UPB_SRC = 2 * UPB_T + UPB_K - 2;
 template <typename T, int CC>
 __global__ __launch_bounds__(EW_THREADS) void up_bwd_tiled_kernel(const T* __restrict__ dout, T* __restrict__ dlow,
                                                                   int B, int h, int w, int C, int Csrc, float sy,
-                                                                  float sx, int tiles_x, int tiles_y) {
+                                                                  float sx, int tiles_x, int tiles_y,
+                                                                  const float* __restrict__ noise) {
   constexpr int G = 16 / (int)sizeof(T);
   constexpr int VC = CC / G;
   constexpr int PITCH = VC * 16 + 16;
@@ -339,6 +355,10 @@ __global__ __launch_bounds__(EW_THREADS) void up_bwd_tiled_kernel(const T* __res
 #pragma unroll
       for (int k = 0; k < G; k++) acc[k] += wy[ky] * row[k];
     }
+    if (noise) {
+#pragma unroll
+      for (int k = 0; k < G; k++) acc[k] = to_f32(from_f32<T>(acc[k])) * noise[(int64_t)b * C + ch + k];
+    }
     vstore<T, G>(dlow + (((int64_t)b * h + yl) * w + xl) * C + ch, acc);
   }
 }
@@ -347,7 +367,8 @@ __global__ __launch_bounds__(EW_THREADS) void up_bwd_tiled_kernel(const T* __res
 template <typename T>
 __global__ __launch_bounds__(EW_THREADS) void up_fwd_scalar_kernel(const T* __restrict__ low, T* __restrict__ out,
                                                                    int B, int h, int w, int C, int Cdst, float sy,
-                                                                   float sx, const float* __restrict__ low_aff) {
+                                                                   float sx, const float* __restrict__ low_aff,
+                                                                   const float* __restrict__ noise) {
   const int Ho = 2 * h, Wo = 2 * w;
   const int64_t total = (int64_t)B * Ho * Wo * C;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
@@ -368,6 +389,10 @@ __global__ __launch_bounds__(EW_THREADS) void up_fwd_scalar_kernel(const T* __re
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = to_f32(from_f32<T>(fmaxf(v[k] * low_aff[c] + low_aff[C + c], 0.f)));
     }
+    if (noise) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = to_f32(from_f32<T>(v[k] * noise[(int64_t)b * C + c]));
+    }
     out[(((int64_t)b * Ho + yo) * Wo + xo) * Cdst + c] =
         from_f32<T>(hy0 * (wx0 * v[0] + wx1 * v[1]) + hy1 * (wx0 * v[2] + wx1 * v[3]));
   }
@@ -377,7 +402,8 @@ __global__ __launch_bounds__(EW_THREADS) void up_fwd_scalar_kernel(const T* __re
 // high-res pixel whose taps touch it (|offset| <= 4 rows/cols), with the forward's weights.
 template <typename T, int V>
 __global__ __launch_bounds__(EW_THREADS) void up_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dlow, int B,
-                                                            int h, int w, int Cup, int Ct, float sy, float sx) {
+                                                            int h, int w, int Cup, int Ct, float sy, float sx,
+                                                            const float* __restrict__ noise) {
   const int Ho = 2 * h, Wo = 2 * w, CV = Cup / V;
   const int64_t total = (int64_t)B * h * w * CV;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
@@ -430,6 +456,10 @@ __global__ __launch_bounds__(EW_THREADS) void up_bwd_kernel(const T* __restrict_
 #pragma unroll
       for (int k = 0; k < V; k++) acc[k] += wy[ky] * row[k];
     }
+    if (noise) {
+#pragma unroll
+      for (int k = 0; k < V; k++) acc[k] = to_f32(from_f32<T>(acc[k])) * noise[(int64_t)b * Cup + cv * V + k];
+    }
     vstore<T, V>(dlow + i * V, acc);
   }
 }
@@ -453,20 +483,21 @@ __global__ __launch_bounds__(EW_THREADS) void copy_channels_kernel(const T* __re
 }
 
 template <typename T>
-int pool_fwd(const void* x, void* y, int B, int H, int W, int C, const float* aff, hipStream_t st) {
+int pool_fwd(const void* x, void* y, int B, int H, int W, int C, const float* aff, const float* noise,
+             hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
   const size_t lds = aff ? 2 * (size_t)C * sizeof(float) : 0;
   if (pick_vec<T>(C, x, y) == N)
-    maxpool_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (T*)y, B, H, W, C, aff);
+    maxpool_fwd_kernel<T, N><<<ew_grid(n / N, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (T*)y, B, H, W, C, aff, noise);
   else
-    maxpool_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (T*)y, B, H, W, C, aff);
+    maxpool_fwd_kernel<T, 1><<<ew_grid(n, EW_THREADS), EW_THREADS, lds, st>>>((const T*)x, (T*)y, B, H, W, C, aff, noise);
   return 0;
 }
 
 template <typename T>
 int pool_bwd(const void* x, const void* dy, const void* add, void* dx, int B, int H, int W, int C, const float* aff,
-             float* bn_sums, void* ws, hipStream_t st) {
+             const float* noise, float* bn_sums, void* ws, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
   const bool vec = pick_vec<T>(C, x, dy, dx, add) == N;
@@ -487,10 +518,10 @@ int pool_bwd(const void* x, const void* dy, const void* add, void* dx, int B, in
   }
   if (vec)
     maxpool_bwd_kernel<T, N><<<grid, EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)add, (T*)dx, B, H, W,
-                                                             C, aff, partials);
+                                                             C, aff, noise, partials);
   else
     maxpool_bwd_kernel<T, 1><<<grid, EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)add, (T*)dx, B, H, W,
-                                                             C, aff, partials);
+                                                             C, aff, noise, partials);
   if (bn_sums) launch_reduce_partials(partials, grid, 2 * C, bn_sums, st);
   return 0;
 }
@@ -499,7 +530,7 @@ inline float up_scale(int n_in) { return (2 * n_in > 1) ? (float)(n_in - 1) / (f
 
 template <typename T>
 int upcat_fwd(const void* low, const void* skip, void* out, int B, int h, int w, int Cup, int Cskip,
-              const float* low_aff, const float* skip_aff, hipStream_t st) {
+              const float* low_aff, const float* skip_aff, const float* noise, hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int Ct = Cup + Cskip;
   const bool vec = (Cup % N == 0) && (Cskip % N == 0) && pick_vec<T>(Ct, low, skip, out) == N;
@@ -510,17 +541,17 @@ int upcat_fwd(const void* low, const void* skip, void* out, int B, int h, int w,
       constexpr int CC = 8 * N;
       dim3 grid(B * tiles_x * tiles_y, Cup / CC);
       up_fwd_tiled_kernel<T, CC><<<grid, EW_THREADS, 0, st>>>((const T*)low, (T*)out, B, h, w, Cup, Ct, up_scale(h),
-                                                              up_scale(w), tiles_x, tiles_y, low_aff);
+                                                              up_scale(w), tiles_x, tiles_y, low_aff, noise);
     } else {
       constexpr int CC = 4 * N;
       dim3 grid(B * tiles_x * tiles_y, (Cup + CC - 1) / CC);
       up_fwd_tiled_kernel<T, CC><<<grid, EW_THREADS, 0, st>>>((const T*)low, (T*)out, B, h, w, Cup, Ct, up_scale(h),
-                                                              up_scale(w), tiles_x, tiles_y, low_aff);
+                                                              up_scale(w), tiles_x, tiles_y, low_aff, noise);
     }
   } else {
     const int64_t n = (int64_t)B * 4 * h * w * Cup;
     up_fwd_scalar_kernel<T><<<ew_grid(n, EW_THREADS), EW_THREADS, 0, st>>>((const T*)low, (T*)out, B, h, w, Cup, Ct,
-                                                                           up_scale(h), up_scale(w), low_aff);
+                                                                           up_scale(h), up_scale(w), low_aff, noise);
   }
   if (Cskip > 0) {
     const int64_t npix = (int64_t)B * 4 * h * w;
@@ -536,7 +567,8 @@ int upcat_fwd(const void* low, const void* skip, void* out, int B, int h, int w,
 }
 
 template <typename T>
-int upcat_bwd(const void* dout, void* dlow, void* dskip, int B, int h, int w, int Cup, int Cskip, hipStream_t st) {
+int upcat_bwd(const void* dout, void* dlow, void* dskip, int B, int h, int w, int Cup, int Cskip, const float* noise,
+              hipStream_t st) {
   constexpr int N = VecOf<T>::N;
   const int Ct = Cup + Cskip;
   const bool vec = (Cup % N == 0) && (Cskip % N == 0) && pick_vec<T>(Ct, dout, dlow, dskip) == N;
@@ -549,19 +581,19 @@ int upcat_bwd(const void* dout, void* dlow, void* dskip, int B, int h, int w, in
       constexpr int CC = 8 * N;
       const size_t lds = (size_t)UPB_SRC * UPB_SRC * (CC / N * 16 + 16);
       up_bwd_tiled_kernel<T, CC><<<dim3(B * tiles_x * tiles_y, Cup / CC), EW_THREADS, lds, st>>>(
-          (const T*)dout, (T*)dlow, B, h, w, Cup, Ct, up_scale(h), up_scale(w), tiles_x, tiles_y);
+          (const T*)dout, (T*)dlow, B, h, w, Cup, Ct, up_scale(h), up_scale(w), tiles_x, tiles_y, noise);
     } else {
       constexpr int CC = 4 * N;
       const size_t lds = (size_t)UPB_SRC * UPB_SRC * (CC / N * 16 + 16);
       up_bwd_tiled_kernel<T, CC><<<dim3(B * tiles_x * tiles_y, (Cup + CC - 1) / CC), EW_THREADS, lds, st>>>(
-          (const T*)dout, (T*)dlow, B, h, w, Cup, Ct, up_scale(h), up_scale(w), tiles_x, tiles_y);
+          (const T*)dout, (T*)dlow, B, h, w, Cup, Ct, up_scale(h), up_scale(w), tiles_x, tiles_y, noise);
     }
     if (dskip && Cskip > 0)
       copy_channels_kernel<T, N><<<ew_grid(npix * Cskip / N, EW_THREADS), EW_THREADS, 0, st>>>(
           (const T*)dout, (T*)dskip, npix, Ct, Cup, Cskip, 0, Cskip, nullptr);
   } else {
     up_bwd_kernel<T, 1><<<ew_grid(nl, EW_THREADS), EW_THREADS, 0, st>>>((const T*)dout, (T*)dlow, B, h, w, Cup, Ct,
-                                                                          up_scale(h), up_scale(w));
+                                                                          up_scale(h), up_scale(w), noise);
     if (dskip && Cskip > 0)
       copy_channels_kernel<T, 1><<<ew_grid(npix * Cskip, EW_THREADS), EW_THREADS, 0, st>>>(
           (const T*)dout, (T*)dskip, npix, Ct, Cup, Cskip, 0, Cskip, nullptr);
@@ -573,14 +605,14 @@ int upcat_bwd(const void* dout, void* dlow, void* dskip, int B, int h, int w, in
 
 extern "C" {
 
-int mis_maxpool2x2_fwd(const void* x, const float* x_affine, int dtype, int B, int H, int W, int C, void* y,
-                       mis_stream_t stream) {
+int mis_maxpool2x2_fwd(const void* x, const float* x_affine, const float* noise, int dtype, int B, int H, int W, int C,
+                       void* y, mis_stream_t stream) {
   MIS_REQUIRE(x && y, "maxpool2x2_fwd: null pointer");
   MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
               "maxpool2x2_fwd: H and W must be even and >= 2 (got %dx%d)", H, W);
   MIS_REQUIRE(C <= 4096, "maxpool2x2_fwd: C too large");
-  if (dtype == MIS_F32) pool_fwd<float>(x, y, B, H, W, C, x_affine, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) pool_fwd<bf16>(x, y, B, H, W, C, x_affine, (hipStream_t)stream);
+  if (dtype == MIS_F32) pool_fwd<float>(x, y, B, H, W, C, x_affine, noise, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) pool_fwd<bf16>(x, y, B, H, W, C, x_affine, noise, (hipStream_t)stream);
   else MIS_REQUIRE(false, "maxpool2x2_fwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("maxpool_fwd_kernel");
   return MIS_OK;
@@ -590,40 +622,42 @@ size_t mis_maxpool2x2_bwd_workspace_bytes(int C) {
   return C < 1 ? 0 : align256((size_t)POOL_MAX_ROWS * 2 * C * sizeof(float));
 }
 
-int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const void* dy, const void* dx_add, int dtype, int B,
-                       int H, int W, int C, void* dx, float* bn_sums, void* workspace, mis_stream_t stream) {
+int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const float* noise, const void* dy, const void* dx_add,
+                       int dtype, int B, int H, int W, int C, void* dx, float* bn_sums, void* workspace,
+                       mis_stream_t stream) {
   MIS_REQUIRE(x && dy && dx, "maxpool2x2_bwd: null pointer");
   MIS_REQUIRE(!bn_sums || (x_affine && workspace), "maxpool2x2_bwd: bn_sums needs the [4][C] affine and a workspace");
   MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
               "maxpool2x2_bwd: H and W must be even and >= 2 (got %dx%d)", H, W);
   MIS_REQUIRE(C <= 4096, "maxpool2x2_bwd: C too large");
-  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx_add, dx, B, H, W, C, x_affine, bn_sums, workspace, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx_add, dx, B, H, W, C, x_affine, bn_sums, workspace, (hipStream_t)stream);
+  if (dtype == MIS_F32) pool_bwd<float>(x, dy, dx_add, dx, B, H, W, C, x_affine, noise, bn_sums, workspace, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx_add, dx, B, H, W, C, x_affine, noise, bn_sums, workspace, (hipStream_t)stream);
   else MIS_REQUIRE(false, "maxpool2x2_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("maxpool_bwd_kernel");
   return MIS_OK;
 }
 
-int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const void* skip, const float* skip_affine,
-                           int dtype, int B, int h, int w, int Cup, int Cskip, void* out, mis_stream_t stream) {
+int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const float* low_noise, const void* skip,
+                           const float* skip_affine, int dtype, int B, int h, int w, int Cup, int Cskip, void* out,
+                           mis_stream_t stream) {
   MIS_REQUIRE(low && out && (skip || Cskip == 0), "upsample2x_cat_fwd: null pointer");
   MIS_REQUIRE(B >= 1 && h >= 1 && w >= 1 && Cup >= 1 && Cskip >= 0, "upsample2x_cat_fwd: bad shape");
   MIS_REQUIRE(Cup + Cskip <= 4096, "upsample2x_cat_fwd: too many channels");
   if (dtype == MIS_F32)
-    upcat_fwd<float>(low, skip, out, B, h, w, Cup, Cskip, low_affine, skip_affine, (hipStream_t)stream);
+    upcat_fwd<float>(low, skip, out, B, h, w, Cup, Cskip, low_affine, skip_affine, low_noise, (hipStream_t)stream);
   else if (dtype == MIS_BF16)
-    upcat_fwd<bf16>(low, skip, out, B, h, w, Cup, Cskip, low_affine, skip_affine, (hipStream_t)stream);
+    upcat_fwd<bf16>(low, skip, out, B, h, w, Cup, Cskip, low_affine, skip_affine, low_noise, (hipStream_t)stream);
   else MIS_REQUIRE(false, "upsample2x_cat_fwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("up_fwd_tiled_kernel");
   return MIS_OK;
 }
 
-int mis_upsample2x_cat_bwd(const void* dout, int dtype, int B, int h, int w, int Cup, int Cskip, void* dlow,
-                           void* dskip, mis_stream_t stream) {
+int mis_upsample2x_cat_bwd(const void* dout, const float* low_noise, int dtype, int B, int h, int w, int Cup, int Cskip,
+                           void* dlow, void* dskip, mis_stream_t stream) {
   MIS_REQUIRE(dout && dlow && (dskip || Cskip == 0), "upsample2x_cat_bwd: null pointer");
   MIS_REQUIRE(B >= 1 && h >= 1 && w >= 1 && Cup >= 1 && Cskip >= 0, "upsample2x_cat_bwd: bad shape");
-  if (dtype == MIS_F32) upcat_bwd<float>(dout, dlow, dskip, B, h, w, Cup, Cskip, (hipStream_t)stream);
-  else if (dtype == MIS_BF16) upcat_bwd<bf16>(dout, dlow, dskip, B, h, w, Cup, Cskip, (hipStream_t)stream);
+  if (dtype == MIS_F32) upcat_bwd<float>(dout, dlow, dskip, B, h, w, Cup, Cskip, low_noise, (hipStream_t)stream);
+  else if (dtype == MIS_BF16) upcat_bwd<bf16>(dout, dlow, dskip, B, h, w, Cup, Cskip, low_noise, (hipStream_t)stream);
   else MIS_REQUIRE(false, "upsample2x_cat_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("up_bwd_tiled_kernel");
   return MIS_OK;

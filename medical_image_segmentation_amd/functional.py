@@ -387,18 +387,39 @@ def conv_bn_relu(x, x_ss, conv, bn, training, x2=None, x2_ss=None):
 # ---------------------------------------------------------------------------
 # Down / Up   (model/unet.py:19-20, 48-81)
 # ---------------------------------------------------------------------------
-def _maxpool_fwd(x, x_ss):
+def dropout2d_noise(layer, x):
+    """The multiplier of an nn.Dropout2d `layer` for activation x: None when it is the identity
+    (p == 0 or eval mode), else a float32 [B, C, 1, 1] tensor of 0 / 1/(1-p) per (sample, channel),
+    drawn exactly as torch's feature dropout draws it (bernoulli_(1-p) on the device generator),
+    so a run seeded like a torch run drops the same feature maps.  The Down/Up kernels apply it."""
+    p = float(layer.p)
+    if p == 0.0 or not layer.training:
+        return None
+    B, Cc = x.shape[0], x.shape[1]
+    if p >= 1.0:
+        return torch.zeros((B, Cc, 1, 1), dtype=torch.float32, device=x.device)
+    return torch.empty((B, Cc, 1, 1), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
+def _check_noise(noise, B, Cc):
+    if noise is not None and (noise.dtype != torch.float32 or noise.numel() != B * Cc or not noise.is_contiguous()):
+        raise ValueError(f"dropout noise must be a contiguous float32 tensor of {B}x{Cc} elements")
+    return noise
+
+
+def _maxpool_fwd(x, x_ss, noise=None):
     _check_act(x)
     B, Cc, H, W = x.shape
     if H % 2 or W % 2:
         raise ValueError(f"max-pool 2x2 needs even H and W, got {H}x{W}")
+    _check_noise(noise, B, Cc)
     y = _empty_act(B, Cc, H // 2, W // 2, x)
     with _prof("maxpool2x2_fwd", 0, (x.numel() + y.numel()) * x.element_size()):
-        call("mis_maxpool2x2_fwd", x.data_ptr(), _p(x_ss), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
+        call("mis_maxpool2x2_fwd", x.data_ptr(), _p(x_ss), _p(noise), _dt(x), B, H, W, Cc, y.data_ptr(), _stream())
     return y
 
 
-def _maxpool_bwd(x, x_ss, dy, dx_add=None):
+def _maxpool_bwd(x, x_ss, dy, dx_add=None, noise=None):
     """Gradient of the pooled activation routed to each window's first maximum, plus `dx_add`
     (a second gradient of the same tensor); autograd's gradient buffers are never written."""
     B, Cc, H, W = x.shape
@@ -412,100 +433,110 @@ def _maxpool_bwd(x, x_ss, dy, dx_add=None):
         sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
         ws = workspace(query("mis_maxpool2x2_bwd_workspace_bytes", Cc), x.device)
     with _prof("maxpool2x2_bwd", 0, nbytes):
-        call("mis_maxpool2x2_bwd", x.data_ptr(), _p(x_ss), dy.data_ptr(), _p(dx_add), _dt(x), B, H, W, Cc,
+        call("mis_maxpool2x2_bwd", x.data_ptr(), _p(x_ss), _p(noise), dy.data_ptr(), _p(dx_add), _dt(x), B, H, W, Cc,
              dx.data_ptr(), _p(sums), _p(ws), _stream())
     return attach_bn_sums(dx, sums, x) if sums is not None else dx
 
 
 class MaxPool2x2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) of a lazy or plain activation, optionally followed by nn.Dropout2d
+    (`noise` from `dropout2d_noise`) — unet.py:48-61."""
+
     @staticmethod
-    def forward(ctx, x, x_ss):
-        y = _maxpool_fwd(x, x_ss)
-        ctx.save_for_backward(x, x_ss)
+    def forward(ctx, x, x_ss, noise=None):
+        y = _maxpool_fwd(x, x_ss, noise)
+        ctx.save_for_backward(x, x_ss, noise)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, x_ss = ctx.saved_tensors
-        return _maxpool_bwd(x, x_ss, dy), None
+        x, x_ss, noise = ctx.saved_tensors
+        return _maxpool_bwd(x, x_ss, dy, None, noise), None, None
 
 
 class PoolSkipFn(torch.autograd.Function):
-    """An encoder output used twice: max-pooled for the next level, and (as the very same
-    tensor) as the decoder's skip connection — unet.py:47-60,67-81.  (x, x_ss) -> (pooled, skip)
-    with skip an alias of x; the backward receives both gradients at once and sums them inside
-    the pooling backward kernel."""
+    """An encoder output used twice: max-pooled (then Dropout2d, `noise`) for the next level,
+    and (as the very same tensor) as the decoder's skip connection — unet.py:47-60,67-81.
+    (x, x_ss) -> (pooled, skip) with skip an alias of x; the backward receives both gradients at
+    once and sums them inside the pooling backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, x_ss):
-        y = _maxpool_fwd(x, x_ss)
-        ctx.save_for_backward(x, x_ss)
+    def forward(ctx, x, x_ss, noise=None):
+        y = _maxpool_fwd(x, x_ss, noise)
+        ctx.save_for_backward(x, x_ss, noise)
         ctx.set_materialize_grads(False)
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dskip):
-        x, x_ss = ctx.saved_tensors
+        x, x_ss, noise = ctx.saved_tensors
         if dy is None:
-            return dskip, None
-        return _maxpool_bwd(x, x_ss, dy, dskip), None
+            return dskip, None, None
+        return _maxpool_bwd(x, x_ss, dy, dskip, noise), None, None
 
 
 class UpsampleCatFn(torch.autograd.Function):
-    """cat([bilinear_x2(low), skip], dim=1) — upsampled channels first (unet.py:66-67); either
-    input may be a lazy activation."""
+    """cat([bilinear_x2(dropout2d(low)), skip], dim=1) — upsampled channels first
+    (unet.py:66-67); either input may be a lazy activation, `noise` is the Dropout2d multiplier
+    of `low` (unet.py:64,69,74) or None."""
 
     @staticmethod
-    def forward(ctx, low, low_ss, skip, skip_ss):
+    def forward(ctx, low, low_ss, skip, skip_ss, noise=None):
         _check_act(low, "low")
         _check_act(skip, "skip")
         B, Cup, h, w = low.shape
         Bs, Cskip, Hs, Ws = skip.shape
         if (Bs, Hs, Ws) != (B, 2 * h, 2 * w) or skip.dtype != low.dtype:
             raise ValueError(f"skip {tuple(skip.shape)} does not match upsampled {(B, Cup, 2 * h, 2 * w)}")
+        _check_noise(noise, B, Cup)
         out = _empty_act(B, Cup + Cskip, 2 * h, 2 * w, low)
         with _prof("upsample2x_cat_fwd", 0, (low.numel() + skip.numel() + out.numel()) * low.element_size()):
-            call("mis_upsample2x_cat_fwd", low.data_ptr(), _p(low_ss), skip.data_ptr(), _p(skip_ss), _dt(low), B, h, w,
-                 Cup, Cskip, out.data_ptr(), _stream())
+            call("mis_upsample2x_cat_fwd", low.data_ptr(), _p(low_ss), _p(noise), skip.data_ptr(), _p(skip_ss),
+                 _dt(low), B, h, w, Cup, Cskip, out.data_ptr(), _stream())
         ctx.dims = (B, h, w, Cup, Cskip)
+        ctx.save_for_backward(noise)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         B, h, w, Cup, Cskip = ctx.dims
+        noise, = ctx.saved_tensors
         dout = to_act(dout)
         dlow = _empty_act(B, Cup, h, w, dout)
         dskip = _empty_act(B, Cskip, 2 * h, 2 * w, dout)
         with _prof("upsample2x_cat_bwd", 0, (dout.numel() + dlow.numel() + dskip.numel()) * dout.element_size()):
-            call("mis_upsample2x_cat_bwd", dout.data_ptr(), _dt(dout), B, h, w, Cup, Cskip, dlow.data_ptr(),
-                 dskip.data_ptr(), _stream())
-        return dlow, None, dskip, None
+            call("mis_upsample2x_cat_bwd", dout.data_ptr(), _p(noise), _dt(dout), B, h, w, Cup, Cskip,
+                 dlow.data_ptr(), dskip.data_ptr(), _stream())
+        return dlow, None, dskip, None, None
 
 
 class UpsampleFn(torch.autograd.Function):
-    """bilinear x2 (align_corners=True) of a lazy or plain activation — unet.py:20,66 — for the
-    decoder convs that read [up | skip] as two tensors."""
+    """bilinear x2 (align_corners=True) of a lazy or plain activation (after its Dropout2d, when
+    `noise` is given) — unet.py:20,66 — for the decoder convs that read [up | skip] as two tensors."""
 
     @staticmethod
-    def forward(ctx, low, low_ss):
+    def forward(ctx, low, low_ss, noise=None):
         _check_act(low, "low")
         B, Cup, h, w = low.shape
+        _check_noise(noise, B, Cup)
         out = _empty_act(B, Cup, 2 * h, 2 * w, low)
         with _prof("upsample2x_cat_fwd", 0, (low.numel() + out.numel()) * low.element_size()):
-            call("mis_upsample2x_cat_fwd", low.data_ptr(), _p(low_ss), None, None, _dt(low), B, h, w, Cup, 0,
-                 out.data_ptr(), _stream())
+            call("mis_upsample2x_cat_fwd", low.data_ptr(), _p(low_ss), _p(noise), None, None, _dt(low), B, h, w, Cup,
+                 0, out.data_ptr(), _stream())
         ctx.dims = (B, h, w, Cup)
+        ctx.save_for_backward(noise)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         B, h, w, Cup = ctx.dims
+        noise, = ctx.saved_tensors
         dout = to_act(dout)
         dlow = _empty_act(B, Cup, h, w, dout)
         with _prof("upsample2x_cat_bwd", 0, (dout.numel() + dlow.numel()) * dout.element_size()):
-            call("mis_upsample2x_cat_bwd", dout.data_ptr(), _dt(dout), B, h, w, Cup, 0, dlow.data_ptr(), None,
-                 _stream())
-        return dlow, None
+            call("mis_upsample2x_cat_bwd", dout.data_ptr(), _p(noise), _dt(dout), B, h, w, Cup, 0, dlow.data_ptr(),
+                 None, _stream())
+        return dlow, None, None
 
 
 class Conv1x1Fn(torch.autograd.Function):

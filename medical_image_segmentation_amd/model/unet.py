@@ -48,57 +48,44 @@ class UNet(nn.Module):
             return self.compute_dtype
         return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
 
-    @staticmethod
-    def _drop(layer, x):
-        # Dropout2d draws one Bernoulli per (sample, channel); with p == 0 (every parity
-        # configuration, predict.py:185) it is the identity and no kernel runs.
-        if layer.p == 0 or not layer.training:
-            return x
-        return layer(x)
-
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError(f"expected [B, {self.in_channels}, H, W], got {tuple(x.shape)}")
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
-        down, upcat = F_.PoolSkipFn.apply, F_.UpsampleCatFn.apply
-        drop = self._drop
+        down, noise = F_.PoolSkipFn.apply, F_.dropout2d_noise
         x = F_.to_act(x, self._dtype())
         # every DoubleConv output stays lazy (z, ss): pool, upsample+concat, the next conv and the
         # 1x1 head apply its BatchNorm affine + ReLU while loading it.  `down` returns the pooled
         # tensor and the skip alias of its input, so both gradients meet in one kernel.
+        # Dropout2d (identity at p == 0 / eval: no noise tensor, no extra work) is one multiplier per
+        # (sample, channel): the kernel that consumes the dropped tensor's source applies it — the
+        # pooling for the encoder dropouts, the upsampling for the center / decoder ones.  The
+        # noise tensors are drawn in the reference's order (unet.py:49-74).
         z1, s1 = self.encoder1.forward_lazy(x)
-        p1, z1 = down(z1, s1)
-        z2, s2 = self.encoder2.forward_lazy(drop(self.encoder_dropout1, p1))
-        p2, z2 = down(z2, s2)
-        z3, s3 = self.encoder3.forward_lazy(drop(self.encoder_dropout2, p2))
-        p3, z3 = down(z3, s3)
-        z4, s4 = self.encoder4.forward_lazy(drop(self.encoder_dropout3, p3))
-        p4, z4 = down(z4, s4)
-        x5 = drop(self.encoder_dropout4, p4)
-        y, sy = self._lazy_drop(self.bottleneck_dropout, *self.center_conv.forward_lazy(x5))
-        y, sy = self._lazy_drop(self.decoder_dropout1, *self._up(self.decoder1, y, sy, z4, s4))
-        y, sy = self._lazy_drop(self.decoder_dropout2, *self._up(self.decoder2, y, sy, z3, s3))
-        y, sy = self._up(self.decoder3, y, sy, z2, s2)
-        y, sy = self._up(self.decoder4, y, sy, z1, s1)
+        p1, z1 = down(z1, s1, noise(self.encoder_dropout1, z1))
+        z2, s2 = self.encoder2.forward_lazy(p1)
+        p2, z2 = down(z2, s2, noise(self.encoder_dropout2, z2))
+        z3, s3 = self.encoder3.forward_lazy(p2)
+        p3, z3 = down(z3, s3, noise(self.encoder_dropout3, z3))
+        z4, s4 = self.encoder4.forward_lazy(p3)
+        p4, z4 = down(z4, s4, noise(self.encoder_dropout4, z4))
+        y, sy = self.center_conv.forward_lazy(p4)
+        y, sy = self._up(self.decoder1, y, sy, z4, s4, noise(self.bottleneck_dropout, y))
+        y, sy = self._up(self.decoder2, y, sy, z3, s3, noise(self.decoder_dropout1, y))
+        y, sy = self._up(self.decoder3, y, sy, z2, s2, noise(self.decoder_dropout2, y))
+        y, sy = self._up(self.decoder4, y, sy, z1, s1, None)
         return F_.Conv1x1Fn.apply(y, sy, self.out_conv.weight, self.out_conv.bias)
 
     @staticmethod
-    def _up(block, low, low_ss, skip, skip_ss):
-        """x = up(low); x = cat([x, skip], 1); x = block(x) — unet.py:66-68.  Where the conv
-        kernels take two input tensors the concatenation is virtual: only the upsampled half is
-        written, the skip is read in place (lazily) by the conv and its weight gradient, and the
-        data gradient comes back as two tensors."""
+    def _up(block, low, low_ss, skip, skip_ss, low_noise):
+        """x = up(dropout(low)); x = cat([x, skip], 1); x = block(x) — unet.py:64-68.  Where the
+        conv kernels take two input tensors the concatenation is virtual: only the upsampled half
+        is written, the skip is read in place (lazily) by the conv and its weight gradient, and
+        the data gradient comes back as two tensors."""
         if F_.cat_supported(skip, skip, block.cbr1[0].out_channels) and low.shape[1] == skip.shape[1]:
-            return block.forward_lazy(F_.UpsampleFn.apply(low, low_ss), None, skip, skip_ss)
-        return block.forward_lazy(F_.UpsampleCatFn.apply(low, low_ss, skip, skip_ss))
-
-    @staticmethod
-    def _lazy_drop(layer, z, ss):
-        """Dropout on a lazy activation: identity at p == 0 / eval; otherwise materialise first."""
-        if layer.p == 0 or not layer.training:
-            return z, ss
-        return layer(F_.materialize(z, ss)), None
+            return block.forward_lazy(F_.UpsampleFn.apply(low, low_ss, low_noise), None, skip, skip_ss)
+        return block.forward_lazy(F_.UpsampleCatFn.apply(low, low_ss, skip, skip_ss, low_noise))
 
     def elastic_net(self, l1_lambda, l2_lambda):
         l1_loss = 0

@@ -168,17 +168,20 @@ def param_keys(state):
     return [k for k in state if k.endswith(PARAM_SUFFIXES) or k.startswith("out_conv.")]
 
 
-def unet_forward(x, state, training=True, update_stats=True):
-    """UNet.forward with every Dropout2d at p=0 — unet.py:46-85."""
+def unet_forward(x, state, training=True, update_stats=True, noise=None):
+    """UNet.forward — unet.py:46-85.  `noise`: None (every Dropout2d at p=0 / eval) or the 7
+    Dropout2d multipliers [B, C, 1, 1] (0 or 1/(1-p) per sample and channel) in call order:
+    encoder_dropout1-4, bottleneck_dropout, decoder_dropout1-2 (unet.py:49,53,57,61,64,69,74)."""
     dc = lambda t, name: double_conv(t, state, name, training, update_stats)
+    dr = (lambda t, i: t) if noise is None else (lambda t, i: t * noise[i].to(t.dtype))
     x1 = dc(x, "encoder1")
-    x2 = dc(maxpool2x2(x1), "encoder2")
-    x3 = dc(maxpool2x2(x2), "encoder3")
-    x4 = dc(maxpool2x2(x3), "encoder4")
-    x5 = maxpool2x2(x4)
-    y = dc(x5, "center_conv")
-    y = dc(torch.cat([upsample2x_bilinear(y), x4], dim=1), "decoder1")
-    y = dc(torch.cat([upsample2x_bilinear(y), x3], dim=1), "decoder2")
+    x2 = dc(dr(maxpool2x2(x1), 0), "encoder2")
+    x3 = dc(dr(maxpool2x2(x2), 1), "encoder3")
+    x4 = dc(dr(maxpool2x2(x3), 2), "encoder4")
+    x5 = dr(maxpool2x2(x4), 3)
+    y = dr(dc(x5, "center_conv"), 4)
+    y = dr(dc(torch.cat([upsample2x_bilinear(y), x4], dim=1), "decoder1"), 5)
+    y = dr(dc(torch.cat([upsample2x_bilinear(y), x3], dim=1), "decoder2"), 6)
     y = dc(torch.cat([upsample2x_bilinear(y), x2], dim=1), "decoder3")
     y = dc(torch.cat([upsample2x_bilinear(y), x1], dim=1), "decoder4")
     return F.conv2d(y, state["out_conv.weight"], state["out_conv.bias"])   # unet.py:44,84

@@ -660,3 +660,79 @@ def test_bn_sums_fused_into_gradient_producer(F_, dtype, consumer):
     tol = 2e-5 if dtype == torch.float32 else 2e-3
     for a, b in zip(*res):
         assert rel_err(a, b) < tol
+
+
+# ---------------------------------------------------------------------------
+# Dropout2d folded into the Down / Up kernels (unet.py:27-42, 49-74)
+# ---------------------------------------------------------------------------
+def _noise(B, C, p, seed):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(B, C, 1, 1, generator=g) >= p).float() / (1.0 - p))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("lazy", [False, True])
+def test_maxpool_dropout(F_, dtype, lazy):
+    B, C, H, W = 3, 16, 12, 20
+    g = torch.Generator().manual_seed(17)
+    x = q(torch.randn(B, C, H, W, generator=g), dtype)
+    gy = q(torch.randn(B, C, H // 2, W // 2, generator=g), dtype)
+    nz = _noise(B, C, 0.4, 3)
+    ss = None
+    if lazy:
+        ss = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3])
+    xd = act(x, dtype).requires_grad_(True)
+    y = F_.MaxPool2x2Fn.apply(xd, None if ss is None else ss.to(DEV), nz.to(DEV))
+    y.backward(act(gy, dtype))
+    xr = x.clone().double().requires_grad_(True)
+    a = xr if ss is None else torch.relu(xr * ss[0].double()[None, :, None, None] + ss[1].double()[None, :, None, None])
+    if lazy and dtype == torch.bfloat16:
+        a = a + (a.detach().to(dtype).double() - a.detach())          # the activation as the kernel rounds it
+    yr = torch.nn.functional.max_pool2d(a, 2, 2) * nz.double()
+    yr.backward(gy.double())
+    assert rel_err(y, yr) < TOL[dtype]
+    if not lazy:
+        assert rel_err(xd.grad, xr.grad) < TOL[dtype]
+    # dropped feature maps are exactly zero, kept ones exactly scaled
+    dropped = (nz[:, :, 0, 0] == 0)
+    assert float(y.detach().float().cpu()[dropped].abs().max()) == 0.0
+    assert float(xd.grad.float().cpu()[dropped].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [16, 64, 6])
+def test_upsample_dropout(F_, dtype, C):
+    B, h, w = 2, 5, 7
+    g = torch.Generator().manual_seed(19)
+    low = q(torch.randn(B, C, h, w, generator=g), dtype)
+    gy = q(torch.randn(B, C, 2 * h, 2 * w, generator=g), dtype)
+    nz = _noise(B, C, 0.3, 5)
+    ld = act(low, dtype).requires_grad_(True)
+    y = F_.UpsampleFn.apply(ld, None, nz.to(DEV))
+    y.backward(act(gy, dtype))
+    lr = low.clone().double().requires_grad_(True)
+    yr = orc.upsample2x_bilinear(lr * nz.double())
+    yr.backward(gy.double())
+    assert rel_err(y, yr) < TOL[dtype]
+    assert rel_err(ld.grad, lr.grad) < TOL[dtype]
+    # and as the head of a materialised concatenation
+    skip = q(torch.randn(B, C, 2 * h, 2 * w, generator=g), dtype)
+    yc = F_.UpsampleCatFn.apply(act(low, dtype), None, act(skip, dtype), None, nz.to(DEV))
+    assert rel_err(yc[:, :C], yr) < TOL[dtype]
+    assert torch.equal(yc[:, C:].cpu(), skip.to(dtype))
+
+
+def test_dropout_noise_is_torch_feature_dropout(F_):
+    """The multiplier is drawn exactly as nn.Dropout2d draws it on this device: same seed, same
+    dropped feature maps."""
+    for p in (0.03, 0.5, 0.9):
+        layer = torch.nn.Dropout2d(p).train()
+        x = torch.ones(5, 37, 4, 4, device=DEV)
+        torch.manual_seed(123)
+        ref = layer(x)
+        torch.manual_seed(123)
+        nz = F_.dropout2d_noise(layer, x)
+        assert nz.shape == (5, 37, 1, 1) and nz.dtype == torch.float32
+        assert torch.equal(ref, x * nz)
+        assert F_.dropout2d_noise(layer.eval(), x) is None
+    assert F_.dropout2d_noise(torch.nn.Dropout2d(0.0).train(), x) is None

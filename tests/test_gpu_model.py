@@ -225,3 +225,65 @@ def test_fused_clip_adamw_matches_torch():
     before = [p.detach().clone() for p in ps]
     clip_and_step(sgd, ps, max_norm=1.0)
     assert all(float((b - p).abs().max()) > 0 for b, p in zip(before, ps))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_dropout_matches_oracle(dtype):
+    """Train-mode forward/backward with Dropout2d active (p = 0.5 -> layer rates 0.15 .. 0.5):
+    the noise tensors the model drew are replayed in the oracle.  float32: logits 1e-4, gradient
+    norms 2 % (one ReLU-mask flip moves them by per cents in this tiny net); bfloat16: loss 1e-2."""
+    from medical_image_segmentation_amd import functional as F_
+    from medical_image_segmentation_amd.model.unet import UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    c = dict(B=2, cin=3, ncls=4, hw=64, seed=22)
+    m = UNet(c["cin"], c["ncls"], 0.5, base_channels=8, compute_dtype=dtype)
+    st = orc.make_state(c["cin"], c["ncls"], base=8, seed=c["seed"])
+    m.load_state_dict({k: v.clone() for k, v in st.items()})
+    m = m.to(DEV).train()
+    assert abs(m.encoder_dropout1.p - 0.15) < 1e-12 and m.bottleneck_dropout.p == 0.5
+    xh = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100))
+    th = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+    drawn = []
+    orig = F_.dropout2d_noise
+
+    def recording(layer, x):
+        n = orig(layer, x)
+        drawn.append(n)
+        return n
+
+    F_.dropout2d_noise = recording
+    try:
+        torch.manual_seed(7)
+        logits = m(xh.to(DEV))
+    finally:
+        F_.dropout2d_noise = orig
+    assert len(drawn) == 7 and all(n is not None for n in drawn)
+    assert any(bool((n == 0).any()) for n in drawn)            # something was actually dropped
+    names = ["a", "b", "c"]
+    ld = diceloss(names)(logits, th.to(DEV))
+    ld["total_loss"].backward()
+
+    keys = orc.param_keys(st)
+    sto = {k: v.clone().double() for k, v in st.items()}
+    for k in keys:
+        sto[k].requires_grad_(True)
+    lo = orc.unet_forward(xh.double(), sto, training=True, noise=[n.cpu().double() for n in drawn])
+    ldo = orc.dice_loss(lo, th, names)
+    ldo["total_loss"].backward()
+    if dtype == torch.float32:
+        assert rel_err(logits, lo) < 1e-4
+        assert abs(float(ld["total_loss"].detach()) - float(ldo["total_loss"])) < 1e-5
+        params = dict(m.named_parameters())
+        for k in keys:
+            if k.endswith(".0.bias") and k != "out_conv.bias":
+                continue
+            a, b = float(params[k].grad.double().norm()), float(sto[k].grad.norm())
+            assert abs(a - b) <= 2e-2 * b + 1e-7, (k, a, b)
+    else:
+        assert abs(float(ld["total_loss"].detach()) - float(ldo["total_loss"])) < 1e-2
+    # eval mode: dropout is the identity and nothing is drawn
+    m.eval()
+    state = torch.cuda.get_rng_state()
+    with torch.no_grad():
+        m(xh.to(DEV))
+    assert torch.equal(state, torch.cuda.get_rng_state())

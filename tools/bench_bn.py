@@ -59,11 +59,11 @@ def main():
         y = torch.empty(B, C, hw // 2, hw // 2, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         add = torch.randn_like(x)
-        tf = timeit(lambda: call("mis_maxpool2x2_fwd", x.data_ptr(), ss.data_ptr(), 1, B, hw, hw, C, y.data_ptr(), st))
+        tf = timeit(lambda: call("mis_maxpool2x2_fwd", x.data_ptr(), ss.data_ptr(), None, 1, B, hw, hw, C, y.data_ptr(), st))
         ss4 = torch.rand(4, C, device=dev)
         sums = torch.empty(2, C, device=dev)
         wsp = F_.workspace(query("mis_maxpool2x2_bwd_workspace_bytes", C), dev)
-        tb = timeit(lambda: call("mis_maxpool2x2_bwd", x.data_ptr(), ss4.data_ptr(), y.data_ptr(), add.data_ptr(), 1, B,
+        tb = timeit(lambda: call("mis_maxpool2x2_bwd", x.data_ptr(), ss4.data_ptr(), None, y.data_ptr(), add.data_ptr(), 1, B,
                                  hw, hw, C, dx.data_ptr(), sums.data_ptr(), wsp.data_ptr(), st))
         mb = x.numel() * 2 / 1e6
         print(f"{name:8s} {C:4d} {hw:4d} {mb:6.1f} | fwd {tf:7.1f} us {1.25 * mb / tf:5.2f} TB/s | bwd(+add) {tb:7.1f} us {3.25 * mb / tb:5.2f} TB/s")
@@ -72,9 +72,9 @@ def main():
         ss = torch.rand(2, C, device=dev)
         out = torch.empty(B, C, 2 * h, 2 * h, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
         dlow = torch.empty_like(low)
-        tf = timeit(lambda: call("mis_upsample2x_cat_fwd", low.data_ptr(), ss.data_ptr(), None, None, 1, B, h, h, C, 0,
+        tf = timeit(lambda: call("mis_upsample2x_cat_fwd", low.data_ptr(), ss.data_ptr(), None, None, None, 1, B, h, h, C, 0,
                                  out.data_ptr(), st))
-        tb = timeit(lambda: call("mis_upsample2x_cat_bwd", out.data_ptr(), 1, B, h, h, C, 0, dlow.data_ptr(), None, st))
+        tb = timeit(lambda: call("mis_upsample2x_cat_bwd", out.data_ptr(), None, 1, B, h, h, C, 0, dlow.data_ptr(), None, st))
         mb = out.numel() * 2 / 1e6
         print(f"{name:8s} {C:4d} {h:4d} {mb:6.1f} | fwd {tf:7.1f} us {1.25 * mb / tf:5.2f} TB/s | bwd {tb:7.1f} us {1.25 * mb / tb:5.2f} TB/s")
 
