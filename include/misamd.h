@@ -45,6 +45,8 @@ enum mis_status {
 };
 
 enum mis_dtype { MIS_F32 = 0, MIS_BF16 = 1 };
+/* region loss formed from the pooled sums: diceloss (utils/loss_fn.py:55-88) or IOULoss (:90-124) */
+enum mis_loss_kind { MIS_LOSS_DICE = 0, MIS_LOSS_IOU = 1 };
 
 /* library / build probe */
 int         mis_version(void);              /* MAJOR*10000 + MINOR*100 + PATCH */
@@ -77,18 +79,21 @@ int mis_loss_metrics_fwd(const void* logits, int dtype, int64_t stride_b, int64_
                          float* sums, float* ce_map, int64_t* cm, int32_t* status,
                          void* workspace, mis_stream_t stream);
 
-/* Dice loss values from the pooled sums — utils/loss_fn.py:81-83.               */
-/* losses float32 [C]: losses[i] = 1 - 2 I_{i+1} / (P_{i+1} + T_{i+1} + smooth)  */
-/* for i < C-1 and losses[C-1] = total = sum_i losses[i] / C.                    */
-int mis_dice_from_sums(const float* sums, int C, float smooth, float* losses, mis_stream_t stream);
+/* Loss values from the pooled sums — utils/loss_fn.py:81-83 (Dice) and          */
+/* :116-118 (IoU).  losses float32 [C]: for i < C-1, with c = i+1 and            */
+/* U = P_c + T_c:  Dice  losses[i] = 1 - 2 I_c / (U + smooth);                   */
+/*                 IoU   losses[i] = 1 - I_c / (U - I_c + smooth);               */
+/* losses[C-1] = total = sum_i losses[i] / C.   kind: enum mis_loss_kind.        */
+int mis_dice_from_sums(const float* sums, int C, float smooth, int kind, float* losses, mis_stream_t stream);
 
 /* Gradient of  sum_i w[i]*losses[i]  (+ sum over pixels of dce*ce_map when dce  */
-/* is not NULL) with respect to the logits; autograd of loss_fn.py:72-83,199-203. */
+/* is not NULL) with respect to the logits; autograd of loss_fn.py:72-83 (or     */
+/* :107-118 for kind = MIS_LOSS_IOU) and :199-203.                               */
 /* w float32 [C] device (upstream gradient of each entry of `losses`);           */
 /* dlogits has the logits' dtype and strides.                                    */
 int mis_loss_bwd(const void* logits, int dtype, int64_t stride_b, int64_t stride_c, int64_t stride_p,
                  const int64_t* target, int B, int C, int HW,
-                 const float* sums, const float* w, float smooth, const float* dce,
+                 const float* sums, const float* w, float smooth, int kind, const float* dce,
                  void* dlogits, mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */

@@ -209,13 +209,14 @@ __global__ __launch_bounds__(1024) void loss_sums_finalize_kernel(const float* _
   }
 }
 
-__global__ void dice_from_sums_kernel(const float* __restrict__ sums, int C, float smooth,
+__global__ void dice_from_sums_kernel(const float* __restrict__ sums, int C, float smooth, int kind,
                                       float* __restrict__ losses) {
   if (threadIdx.x == 0) {
     float tot = 0.f;
     for (int c = 1; c < C; c++) {
       const float I = sums[c], U = sums[C + c] + sums[2 * C + c];
-      const float l = 1.0f - (2.0f * I) / (U + smooth);
+      // Dice: 1 - 2I/(U+s) (loss_fn.py:81-82); IoU: 1 - I/(U-I+s) (loss_fn.py:116-117)
+      const float l = (kind == MIS_LOSS_IOU) ? 1.0f - I / (U - I + smooth) : 1.0f - (2.0f * I) / (U + smooth);
       losses[c - 1] = l;
       tot += l;
     }
@@ -226,17 +227,24 @@ __global__ void dice_from_sums_kernel(const float* __restrict__ sums, int C, flo
 template <typename T, int C, bool NHWC>
 __global__ __launch_bounds__(LM_THREADS) void loss_bwd_kernel(
     const T* __restrict__ logits, int64_t sb, int64_t sc, int64_t sp, const int64_t* __restrict__ target, int HW,
-    const float* __restrict__ sums, const float* __restrict__ w, float smooth, const float* __restrict__ dce,
-    T* __restrict__ dlogits) {
+    const float* __restrict__ sums, const float* __restrict__ w, float smooth, int kind,
+    const float* __restrict__ dce, T* __restrict__ dlogits) {
   __shared__ float cA[C], cB[C];
   const int b = blockIdx.y, tid = threadIdx.x;
   if (tid < C) {
     float a = 0.f, bb = 0.f;
     if (tid > 0) {
       const float k = w[tid - 1] + w[C - 1] / (float)C;
-      const float I = sums[tid], U = sums[C + tid] + sums[2 * C + tid] + smooth;
-      a = -2.0f * k / U;
-      bb = 2.0f * k * I / (U * U);
+      // a = k * dloss/dI, bb = k * dloss/dP  (P enters through U = P + T only)
+      if (kind == MIS_LOSS_IOU) {
+        const float I = sums[tid], U = sums[C + tid] + sums[2 * C + tid], D = U - I + smooth;
+        a = -k * (U + smooth) / (D * D);
+        bb = k * I / (D * D);
+      } else {
+        const float I = sums[tid], U = sums[C + tid] + sums[2 * C + tid] + smooth;
+        a = -2.0f * k / U;
+        bb = 2.0f * k * I / (U * U);
+      }
     }
     cA[tid] = a;
     cB[tid] = bb;
@@ -298,16 +306,17 @@ int launch_fwd(const void* logits, int64_t sb, int64_t sc, int64_t sp, const int
 
 template <typename T, int C>
 int launch_bwd(const void* logits, int64_t sb, int64_t sc, int64_t sp, const int64_t* target, int B, int HW,
-               const float* sums, const float* w, float smooth, const float* dce, void* dlogits, hipStream_t st) {
+               const float* sums, const float* w, float smooth, int kind, const float* dce, void* dlogits,
+               hipStream_t st) {
   dim3 grid(lm_blocks_per_sample(B, HW), B);
   const bool nhwc = (sc == 1 && sp == C && sb % C == 0 && ((uintptr_t)logits % 16) == 0 &&
                      ((uintptr_t)dlogits % 16) == 0);
   if (nhwc)
     loss_bwd_kernel<T, C, true><<<grid, LM_THREADS, 0, st>>>((const T*)logits, sb, sc, sp, target, HW, sums, w,
-                                                             smooth, dce, (T*)dlogits);
+                                                             smooth, kind, dce, (T*)dlogits);
   else
     loss_bwd_kernel<T, C, false><<<grid, LM_THREADS, 0, st>>>((const T*)logits, sb, sc, sp, target, HW, sums, w,
-                                                              smooth, dce, (T*)dlogits);
+                                                              smooth, kind, dce, (T*)dlogits);
   return 0;
 }
 
@@ -369,24 +378,26 @@ int mis_loss_metrics_fwd(const void* logits, int dtype, int64_t sb, int64_t sc, 
   return MIS_OK;
 }
 
-int mis_dice_from_sums(const float* sums, int C, float smooth, float* losses, mis_stream_t stream) {
+int mis_dice_from_sums(const float* sums, int C, float smooth, int kind, float* losses, mis_stream_t stream) {
   MIS_REQUIRE(sums && losses && C >= 2 && C <= 16, "dice_from_sums: bad arguments");
-  dice_from_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(sums, C, smooth, losses);
+  MIS_REQUIRE(kind == MIS_LOSS_DICE || kind == MIS_LOSS_IOU, "dice_from_sums: bad loss kind %d", kind);
+  dice_from_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(sums, C, smooth, kind, losses);
   MIS_CHECK_LAUNCH("dice_from_sums_kernel");
   return MIS_OK;
 }
 
 int mis_loss_bwd(const void* logits, int dtype, int64_t sb, int64_t sc, int64_t sp, const int64_t* target, int B,
-                 int C, int HW, const float* sums, const float* w, float smooth, const float* dce, void* dlogits,
-                 mis_stream_t stream) {
+                 int C, int HW, const float* sums, const float* w, float smooth, int kind, const float* dce,
+                 void* dlogits, mis_stream_t stream) {
   MIS_REQUIRE(logits && target && sums && w && dlogits, "loss_bwd: null pointer");
+  MIS_REQUIRE(kind == MIS_LOSS_DICE || kind == MIS_LOSS_IOU, "loss_bwd: bad loss kind %d", kind);
   MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 2 && C <= 16, "loss_bwd: need B,HW >= 1 and 2 <= C <= 16 (C=%d)", C);
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "loss_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MIS_F32) {
-    DISPATCH_C(launch_bwd, float, C, logits, sb, sc, sp, target, B, HW, sums, w, smooth, dce, dlogits, st)
+    DISPATCH_C(launch_bwd, float, C, logits, sb, sc, sp, target, B, HW, sums, w, smooth, kind, dce, dlogits, st)
   } else {
-    DISPATCH_C(launch_bwd, bf16, C, logits, sb, sc, sp, target, B, HW, sums, w, smooth, dce, dlogits, st)
+    DISPATCH_C(launch_bwd, bf16, C, logits, sb, sc, sp, target, B, HW, sums, w, smooth, kind, dce, dlogits, st)
   }
   MIS_CHECK_LAUNCH("loss_bwd_kernel");
   return MIS_OK;

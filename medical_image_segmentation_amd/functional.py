@@ -618,17 +618,22 @@ def loss_metrics_raw(logits, target, want_sums=True, want_ce=False, want_cm=True
     return sums, ce, cm, status, logits, target
 
 
+LOSS_DICE, LOSS_IOU = 0, 1
+
+
 class DiceLossFn(torch.autograd.Function):
-    """losses[C] = (per-foreground-class Dice losses..., total) and optionally the CE map."""
+    """losses[C] = (per-foreground-class Dice — or IoU, `kind` — losses..., total) and optionally
+    the CE map."""
 
     @staticmethod
-    def forward(ctx, logits, target, smooth, want_ce):
+    def forward(ctx, logits, target, smooth, want_ce, kind=LOSS_DICE):
         sums, ce, cm, status, lg, tg = loss_metrics_raw(logits, target, True, want_ce, True)
         Cc = lg.shape[1]
         losses = torch.empty(Cc, dtype=torch.float32, device=lg.device)
-        call("mis_dice_from_sums", sums.data_ptr(), Cc, smooth, losses.data_ptr(), _stream())
+        call("mis_dice_from_sums", sums.data_ptr(), Cc, smooth, kind, losses.data_ptr(), _stream())
         ctx.save_for_backward(lg, tg, sums)
         ctx.smooth = smooth
+        ctx.kind = kind
         ctx.in_dtype = logits.dtype
         ctx.mark_non_differentiable(cm, status)
         if ce is None:
@@ -651,7 +656,7 @@ class DiceLossFn(torch.autograd.Function):
         dlogits = torch.empty_like(lg)
         with _prof("loss_bwd", 0, B * H * W * (2 * Cc * lg.element_size() + 8)):
             call("mis_loss_bwd", lg.data_ptr(), _dt(lg), sb, sc, sp, tg.data_ptr(), B, Cc, H * W, sums.data_ptr(),
-                 w.data_ptr(), ctx.smooth, dce_p, dlogits.data_ptr(), _stream())
+                 w.data_ptr(), ctx.smooth, ctx.kind, dce_p, dlogits.data_ptr(), _stream())
         if dlogits.dtype != ctx.in_dtype:
             dlogits = dlogits.to(ctx.in_dtype)
-        return dlogits, None, None, None
+        return dlogits, None, None, None, None

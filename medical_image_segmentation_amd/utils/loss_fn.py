@@ -1,4 +1,4 @@
-"""diceloss — drop-in for the reference's utils/loss_fn.py:55-88, plus the per-pixel
+"""diceloss and IOULoss — drop-ins for the reference's utils/loss_fn.py:55-88 and 90-124, plus the per-pixel
 cross-entropy map of utils/loss_fn.py:199-203, both from ONE fused pass over the logits.
 The same pass also counts the confusion matrix; it is attached to the logits tensor so a
 following Metrics.update(logits, targets) does not read the logits again."""
@@ -25,6 +25,22 @@ class diceloss():
         """logits [B, C, H, W] (any float dtype/layout on the GPU), targets [B, H, W] int.
         Returns {class_names[i]: loss_i ..., 'total_loss': sum_i loss_i / C} — 'total_loss' last."""
         losses, _, cm, status = F_.DiceLossFn.apply(logits, targets, float(self.smooth), False)
+        _attach_counts(logits, targets, cm, status)
+        loss_dict = OrderedDict((name, losses[i]) for i, name in enumerate(self.class_names))
+        loss_dict["total_loss"] = losses[logits.shape[1] - 1]
+        return loss_dict
+
+
+class IOULoss():
+    """Drop-in for the reference's utils/loss_fn.py:90-124: same pass, same three pooled sums,
+    loss_i = 1 - I/(P + T - I + smooth)."""
+
+    def __init__(self, class_names, smooth=1e-5):
+        self.smooth = smooth
+        self.class_names = class_names
+
+    def __call__(self, logits, targets):
+        losses, _, cm, status = F_.DiceLossFn.apply(logits, targets, float(self.smooth), False, F_.LOSS_IOU)
         _attach_counts(logits, targets, cm, status)
         loss_dict = OrderedDict((name, losses[i]) for i, name in enumerate(self.class_names))
         loss_dict["total_loss"] = losses[logits.shape[1] - 1]

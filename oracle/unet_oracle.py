@@ -243,6 +243,17 @@ def dice_loss(logits, target, class_names, smooth=1e-5):
     return out
 
 
+def iou_loss(logits, target, class_names, smooth=1e-5):
+    """IOULoss.__call__ — loss_fn.py:98-124: iou = I / (P + T - I + smooth), loss = 1 - iou,
+    total = sum(fg losses) / C; 'total_loss' is the LAST key."""
+    C = logits.shape[1]
+    inter, psum, tsum = dice_sums(logits, target)
+    loss = 1 - inter / (psum + tsum - inter + smooth)
+    out = OrderedDict((name, loss[i]) for i, name in enumerate(class_names))
+    out["total_loss"] = loss.sum() / C
+    return out
+
+
 def ce_map(logits, target, label_smoothing=1e-7):
     """nn.CrossEntropyLoss(label_smoothing=1e-7, reduction='none', ignore_index=0)
     — loss_fn.py:199-203.  Per pixel: (1-ls)*(-logp[t]) + ls*mean_c(-logp[c]);

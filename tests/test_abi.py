@@ -39,7 +39,7 @@ def test_argument_errors_are_reported_not_crashed():
     from medical_image_segmentation_amd import _lib
     lib = _lib.load()
     # null pointers / bad class count are rejected on the host before any launch
-    rc = lib.mis_dice_from_sums(None, 4, 1e-5, None, None)
+    rc = lib.mis_dice_from_sums(None, 4, 1e-5, 0, None, None)
     assert rc == 1 and b"dice_from_sums" in lib.mis_last_error()
     rc = lib.mis_maxpool2x2_fwd(ctypes.c_void_p(16), None, None, 0, 1, 3, 4, 8, ctypes.c_void_p(16), None)
     assert rc == 1 and b"even" in lib.mis_last_error()

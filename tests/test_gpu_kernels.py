@@ -102,6 +102,31 @@ def test_dice_ce_vs_oracle_and_golden(F_, golden, name, dtype, layout):
         assert rel_err(ce, g[f"{name}.ce_map"]) < 1e-5
 
 
+@pytest.mark.parametrize("name", list(mg.loss_cases()))
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_iou_loss_vs_oracle_and_golden(F_, golden, name, dtype):
+    """IOULoss (loss_fn.py:90-124): values against the reference's own (golden) and the oracle,
+    gradient against the oracle's autograd."""
+    g = golden("loss")
+    c = mg.loss_cases()[name]
+    x, t = mg.loss_inputs(c)
+    xq = q(x, dtype)
+    names = [f"c{i}" for i in range(1, c["C"])]
+    from medical_image_segmentation_amd.utils.loss_fn import IOULoss
+    xd = xq.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ld = IOULoss(names)(xd, T(t).to(DEV))
+    assert list(ld.keys()) == names + ["total_loss"]
+    ld["total_loss"].backward()
+    xo = xq.clone().double().requires_grad_(True)
+    lo = orc.iou_loss(xo, T(t), names)
+    lo["total_loss"].backward()
+    got = np.array([float(v.detach()) for v in ld.values()])
+    np.testing.assert_allclose(got, [float(v) for v in lo.values()], rtol=2e-6, atol=2e-6)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(got, g[f"{name}.iou"], rtol=1e-5, atol=1e-6)
+    assert rel_err(xd.grad, xo.grad) < TOL[dtype]
+
+
 def test_ce_gradient(F_):
     c = mg.loss_cases()["loss_c4"]
     x, t = mg.loss_inputs(c)

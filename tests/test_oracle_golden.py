@@ -110,6 +110,9 @@ def test_losses(golden, name):
     ld["total_loss"].backward()
     close([float(v) for v in ld.values()], g[f"{name}.dice"], 1e-6, 1e-7)
     close(xl.grad, g[f"{name}.dice_dlogits"], 1e-4, 1e-9)
+    li = orc.iou_loss(T(x), T(t), names)
+    assert list(li.keys()) == names + ["total_loss"]
+    close([float(v) for v in li.values()], g[f"{name}.iou"], 1e-6, 1e-7)
     ce = orc.ce_map(T(x), T(t))
     close(ce, g[f"{name}.ce_map"], 1e-5, 1e-6)
     # Focal_Loss (loss_fn.py:204-217) rebuilt from the CE map pins that map through the reference class
