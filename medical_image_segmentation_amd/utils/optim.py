@@ -17,17 +17,44 @@ CHUNK = 4096          # MIS_OPT_CHUNK in include/misamd.h
 
 
 class _Plan:
-    """Device table of (param, grad, exp_avg, exp_avg_sq, n) rows and the chunk prefix; rebuilt
-    only when a pointer changed (gradients are usually re-allocated at the same addresses)."""
+    """Device table of (param, grad, exp_avg, exp_avg_sq, n) rows and the chunk prefix of one
+    optimizer.  Gradients are re-allocated every step (`zero_grad()` drops them), at addresses that
+    need not repeat, so the pointer rows are refreshed whenever they changed: written into one of
+    a small ring of pinned staging buffers (allocated once; a slot is reused only after the copy
+    that last read it has completed) and uploaded on the launch stream — no allocation, no host
+    synchronisation.  The chunk prefix depends on the tensor sizes only and is built once."""
+    RING = 4
 
-    def __init__(self):
-        self.key = None
-        self.descs = self.prefix = None
-        self.n_chunks = 0
-        self.group_chunks = []
+    def __init__(self, sizes, group_chunks, prefix, dev):
+        self.sizes = sizes
+        self.group_chunks = group_chunks
+        self.n_chunks = prefix[-1]
+        self.rows = None
+        n = len(sizes)
+        self.descs = torch.empty((n, 5), dtype=torch.int64, device=dev)
+        self.prefix = torch.tensor(prefix, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+        self.stage = [torch.empty((n, 5), dtype=torch.int64).pin_memory() for _ in range(self.RING)]
+        self.done = [None] * self.RING
+        self.slot = 0
+
+    def upload(self, rows):
+        global PLAN_UPLOADS
+        PLAN_UPLOADS += 1
+        k = self.slot
+        self.slot = (k + 1) % self.RING
+        if self.done[k] is not None:
+            self.done[k].synchronize()
+        self.stage[k].copy_(torch.tensor(rows, dtype=torch.int64))
+        self.descs.copy_(self.stage[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[k] = ev
+        self.rows = rows
 
 
-_PLANS = {}
+_PLANS = {}           # id(optimizer) -> _Plan
+PLAN_BUILDS = 0       # tables allocated / pointer-row uploads so far (diagnostics, tests)
+PLAN_UPLOADS = 0
 
 
 def _fusable(optimizer, params):
@@ -86,22 +113,22 @@ def clip_and_step(optimizer, params, max_norm=1.0):
         for p in ps:
             s = optimizer.state[p]
             rows.append((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), p.numel()))
-    plan = _PLANS.setdefault(id(optimizer), _Plan())
-    key = tuple(rows)
-    if plan.key != key:
-        prefix, c = [], 0
-        plan.group_chunks = []
+    sizes = tuple(r[4] for r in rows)
+    plan = _PLANS.get(id(optimizer))
+    if plan is None or plan.sizes != sizes or plan.descs.device != dev:
+        global PLAN_BUILDS
+        PLAN_BUILDS += 1
+        prefix, c, group_chunks = [], 0, []
         for g, ps in groups:
             c0 = c
             for p in ps:
                 prefix.append(c)
                 c += (p.numel() + CHUNK - 1) // CHUNK
-            plan.group_chunks.append((c0, c))
+            group_chunks.append((c0, c))
         prefix.append(c)
-        plan.n_chunks = c
-        plan.descs = torch.tensor(rows, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
-        plan.prefix = torch.tensor(prefix, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
-        plan.key = key
+        plan = _PLANS[id(optimizer)] = _Plan(sizes, group_chunks, prefix, dev)
+    if plan.rows != rows:
+        plan.upload(rows)
     st = torch.cuda.current_stream().cuda_stream
     ws = F_.workspace(query("mis_clip_adamw_workspace_bytes", plan.n_chunks), dev)
     norm = torch.empty((), dtype=torch.float32, device=dev)
