@@ -171,9 +171,14 @@ int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, 
 
 /* dW float32 [Cout][Cin][3][3] = sum_{b,y,x} dz[b,y,x,co] * x[b,y+ky-1,x+kx-1,ci] */
 /* (autograd of nn.Conv2d wrt its weight).  Overwrites dw.                       */
+/* Rider (dbias not NULL): dbias float32 [Cout] = column sums of bias_rows           */
+/* ([n_bias_rows][Cout], the partial rows mis_bn_relu_bwd_dz leaves when its dbias    */
+/* argument equals its workspace) — the conv-bias gradient, reduced by extra          */
+/* workgroups of this call's own reduction launch instead of a launch of its own.     */
 size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W,
-                      int Cin, int Cout, float* dw, void* workspace, mis_stream_t stream);
+                      int Cin, int Cout, float* dw, const float* bias_rows, int n_bias_rows, float* dbias,
+                      void* workspace, mis_stream_t stream);
 
 /* The decoder's `torch.cat([up(x), skip], dim=1)` followed by a 3x3 conv         */
 /* (model/unet.py:66-68, 71-73, 76-78, 80-82) without materialising the          */
@@ -197,7 +202,8 @@ int mis_conv3x3_split_fwd(const void* x, const float* x_affine, const void* w_pa
                           mis_stream_t stream);
 int mis_conv3x3_cat_wgrad(const void* xa, const float* xa_affine, const void* xb, const float* xb_affine,
                           const void* dz, int dtype, int B, int H, int W, int Ca, int Cb, int Cout,
-                          float* dw, void* workspace, mis_stream_t stream);
+                          float* dw, const float* bias_rows, int n_bias_rows, float* dbias, void* workspace,
+                          mis_stream_t stream);
 
 /* Training-mode BatchNorm2d statistics -> per-channel affine + running stats.   */
 /* stats float32 [stats_rows][2][C]: (sum, sum of squares over n = B*H*W values   */
@@ -223,8 +229,11 @@ int mis_bn_relu_apply(const void* z, int dtype, int64_t n_pix, int C, const floa
 /*   dy = da*[y>0], xhat = (z-mean)*rstd;  dbeta = sums[0], dgamma = sums[1].      */
 /* Pass 2 writes  dz = gamma*rstd*(dy - sums0/n - xhat*sums1/n)  and, when dbias is */
 /* not NULL (needs the workspace), dbias[c] = sum over pixels of the stored dz —    */
-/* the gradient of the conv bias that feeds this BatchNorm.                         */
+/* the gradient of the conv bias that feeds this BatchNorm.  With dbias == workspace  */
+/* the partial rows [mis_bn_relu_bwd_dz_rows()][C] are left in the workspace          */
+/* un-reduced for mis_conv3x3_wgrad's rider (tensors must be 16-byte aligned).        */
 size_t mis_bn_relu_bwd_workspace_bytes(int64_t n_pix, int C);
+int mis_bn_relu_bwd_dz_rows(int dtype, int64_t n_pix, int C);
 int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_pix, int C,
                            const float* mean_rstd, const float* gamma, const float* beta,
                            float* sums, void* workspace, mis_stream_t stream);

@@ -41,19 +41,20 @@ PROTOTYPES = {
     "mis_pack_conv3x3_weights_pair": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mis_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "mis_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "mis_clip_adamw_workspace_bytes": (_sz, [_i]),
     "mis_grad_sqsum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mis_clip_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _d, _d, _d, _d, _d, _i64, _i, _vp, _vp]),
     "mis_conv3x3_cat_supported": (_i, [_i] * 7),
     "mis_conv3x3_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_split_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "mis_conv3x3_cat_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_conv3x3_cat_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "mis_bn_finalize": (_i, [_vp, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_eval_affine": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     "mis_bn_relu_apply": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "mis_bn_relu_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_relu_bwd_dz_rows": (_i, [_i, _i64, _i]),
     "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_channel_sum_workspace_bytes": (_sz, [_i64, _i]),
     "mis_channel_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),

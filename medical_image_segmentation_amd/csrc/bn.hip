@@ -16,26 +16,7 @@
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int n,
                                                                int64_t stride, float* __restrict__ out) {
   __shared__ double red[32][33];
-  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + c;
-  double s = 0.0;
-  if (j < n) {
-    int i = r;
-    for (; i + 96 < nblk; i += 128) {
-      const float a0 = partials[(int64_t)i * stride + j], a1 = partials[(int64_t)(i + 32) * stride + j];
-      const float a2 = partials[(int64_t)(i + 64) * stride + j], a3 = partials[(int64_t)(i + 96) * stride + j];
-      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-    }
-    for (; i < nblk; i += 32) s += (double)partials[(int64_t)i * stride + j];
-  }
-  red[r][c] = s;
-  __syncthreads();
-  if (r == 0 && j < n) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 32; k++) t += red[k][c];
-    out[j] = (float)t;
-  }
+  reduce_rows_block(partials, nblk, n, stride, out, blockIdx.x, red);
 }
 
 __global__ __launch_bounds__(1024) void reduce_partials3_kernel(const float* __restrict__ partials, int nblk, int n,
@@ -304,6 +285,10 @@ int bwd_reduce_t(const void* z, const void* da, int64_t n_pix, int C, const floa
   return 0;
 }
 
+static inline int bwd_dz_grid(int64_t n, int C, int V) {
+  return grid_for_fixed_channels(ew_grid(n / V, EW_THREADS), C / V, 1024);
+}
+
 template <typename T>
 int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, const float* mean_rstd,
              const float* gamma, const float* beta, const float* sums, float* dbias, void* ws, hipStream_t st) {
@@ -313,7 +298,7 @@ int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, cons
   const float inv_n = (float)(1.0 / (double)n_pix);
   const bool vec = pick_vec<T>(C, z, da, dz) == N;
   const int V = vec ? N : 1;
-  const int grid = grid_for_fixed_channels(ew_grid(n / V, EW_THREADS), C / V, 1024);
+  const int grid = bwd_dz_grid(n, C, V);
   float* partials = dbias ? (float*)ws : nullptr;
   if (vec)
     bn_relu_bwd_dz_kernel<T, N><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n,
@@ -321,7 +306,9 @@ int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, cons
   else
     bn_relu_bwd_dz_kernel<T, 1><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n, C, inv_n,
                                                                  mean_rstd, gamma, beta, sums, partials);
-  if (dbias) launch_reduce_partials(partials, grid, C, dbias, st);
+  // dbias == workspace: the caller takes the partial rows [grid][C] as they are (and folds
+  // their reduction into a later launch)
+  if (dbias && dbias != partials) launch_reduce_partials(partials, grid, C, dbias, st);
   return 0;
 }
 
@@ -407,6 +394,9 @@ int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, 
   MIS_REQUIRE(z && da && mean_rstd && gamma && beta && sums && dz, "bn_relu_bwd_dz: null pointer");
   MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_dz: bad shape");
   MIS_REQUIRE(!dbias || workspace, "bn_relu_bwd_dz: dbias requested without a workspace");
+  MIS_REQUIRE((const void*)dbias != workspace ||
+                  ((((uintptr_t)z | (uintptr_t)da | (uintptr_t)dz) & 15) == 0),
+              "bn_relu_bwd_dz: partial rows need 16-byte aligned tensors");
   if (dtype == MIS_F32)
     bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream);
   else if (dtype == MIS_BF16)
@@ -414,6 +404,13 @@ int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, 
   else MIS_REQUIRE(false, "bn_relu_bwd_dz: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("bn_relu_bwd_dz_kernel");
   return MIS_OK;
+}
+
+int mis_bn_relu_bwd_dz_rows(int dtype, int64_t n_pix, int C) {
+  if (n_pix < 1 || C < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
+  const int N = dtype == MIS_F32 ? VecOf<float>::N : VecOf<bf16>::N;
+  const int V = (C % N == 0) ? N : 1;
+  return bwd_dz_grid(n_pix * C, C, V);
 }
 
 size_t mis_channel_sum_workspace_bytes(int64_t n_pix, int C) { return red_workspace_bytes(1, C); }

@@ -2,6 +2,7 @@
 // allows it, else the vector-ALU kernel.  MIS_CONV_FORCE_DIRECT=1 in the environment
 // forces the vector-ALU kernels (used by the tests to cross-check the two paths).
 #include "conv_internal.h"
+#include "reduce.h"
 #include <stdlib.h>
 
 static int g_conv_path = -1;   // -1: read MIS_CONV_FORCE_DIRECT once; 0: auto; 1: vector-ALU kernels only
@@ -97,13 +98,19 @@ size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout)
 }
 
 int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W, int Cin,
-                      int Cout, float* dw, void* workspace, mis_stream_t stream) {
+                      int Cout, float* dw, const float* bias_rows, int n_bias_rows, float* dbias, void* workspace,
+                      mis_stream_t stream) {
   MIS_REQUIRE(x && dz && dw && workspace, "conv3x3_wgrad: null pointer");
+  MIS_REQUIRE(!dbias || (bias_rows && n_bias_rows >= 1), "conv3x3_wgrad: dbias needs its partial rows");
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1, "conv3x3_wgrad: bad shape");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_wgrad: bad dtype %d", dtype);
   if (!force_direct() && workspace && conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout))
-    return conv3x3_wgrad_mfma(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, dz, dtype, B, H, W, Cout, dw, workspace,
-                              (hipStream_t)stream);
+    return conv3x3_wgrad_mfma(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, dz, dtype, B, H, W, Cout, dw,
+                              BiasRows{bias_rows, n_bias_rows, dbias}, workspace, (hipStream_t)stream);
+  if (dbias) {
+    launch_reduce_partials(bias_rows, n_bias_rows, Cout, dbias, (hipStream_t)stream);
+    MIS_CHECK_LAUNCH("reduce_partials_kernel");
+  }
   return conv3x3_direct_wgrad(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, workspace, (hipStream_t)stream);
 }
 
@@ -146,16 +153,18 @@ int mis_conv3x3_split_fwd(const void* x, const float* x_affine, const void* w_pa
 
 int mis_conv3x3_cat_wgrad(const void* xa, const float* xa_affine, const void* xb, const float* xb_affine,
                           const void* dz, int dtype, int B, int H, int W, int Ca, int Cb, int Cout, float* dw,
-                          void* workspace, mis_stream_t stream) {
+                          const float* bias_rows, int n_bias_rows, float* dbias, void* workspace,
+                          mis_stream_t stream) {
   MIS_REQUIRE(xa && xb && dz && dw && workspace, "conv3x3_cat_wgrad: null pointer");
+  MIS_REQUIRE(!dbias || (bias_rows && n_bias_rows >= 1), "conv3x3_cat_wgrad: dbias needs its partial rows");
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Ca >= 1 && Cb >= 1 && Cout >= 1, "conv3x3_cat_wgrad: bad shape");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_cat_wgrad: bad dtype %d", dtype);
   if (force_direct() || !conv3x3_wgrad_mfma_cat_supported(dtype, B, H, W, Ca, Cb, Cout)) {
     mis_set_error("conv3x3_cat_wgrad: unsupported channel split %d+%d -> %d", Ca, Cb, Cout);
     return MIS_ERR_UNSUPPORTED;
   }
-  return conv3x3_wgrad_mfma(ConvIn{xa, xa_affine, Ca, xb, xb_affine, Cb}, dz, dtype, B, H, W, Cout, dw, workspace,
-                            (hipStream_t)stream);
+  return conv3x3_wgrad_mfma(ConvIn{xa, xa_affine, Ca, xb, xb_affine, Cb}, dz, dtype, B, H, W, Cout, dw,
+                            BiasRows{bias_rows, n_bias_rows, dbias}, workspace, (hipStream_t)stream);
 }
 
 }  // extern "C"

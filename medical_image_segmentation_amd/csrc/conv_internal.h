@@ -48,5 +48,11 @@ int conv3x3_mfma_pack_pair(const float* w, int Cw_out, int Cw_in, int dtype, voi
 bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
 size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
 bool conv3x3_wgrad_mfma_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout);
+// Optional rider of the weight-gradient reduction: dbias[c] = sum over n_rows rows [n_rows][Cout] of
+// partial conv-bias gradients (left by the BatchNorm backward), reduced by extra workgroups of
+// the same launch.
+struct BiasRows {
+  const float* rows; int n_rows; float* dbias;
+};
 int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, float* dw,
-                       void* workspace, hipStream_t st);
+                       const BiasRows& bias, void* workspace, hipStream_t st);

@@ -1002,8 +1002,14 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
 // (pure streaming) when the weight tensor is large and the splits few.  Fixed order.
 template <int RL>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cin,
-                                                            int Cout, float* __restrict__ dw) {
+                                                            int Cout, float* __restrict__ dw, int nblk_w,
+                                                            BiasRows bias) {
   constexpr int COLS = 1024 / RL;
+  if ((int)blockIdx.x >= nblk_w) {        // rider: the conv-bias gradient from its partial rows
+    __shared__ double bred[32][33];
+    reduce_rows_block(bias.rows, bias.n_rows, Cout, Cout, bias.dbias, (int)blockIdx.x - nblk_w, bred);
+    return;
+  }
   __shared__ double red[RL > 1 ? RL : 1][RL > 1 ? COLS + 1 : 1];
   const int n = 9 * Cin * Cout;
   const int c = threadIdx.x % COLS, r = threadIdx.x / COLS;
@@ -1077,8 +1083,8 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1) 
 }
 
 template <typename T>
-int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, float* dw, void* workspace,
-              hipStream_t st) {
+int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, float* dw, const BiasRows& bias,
+              void* workspace, hipStream_t st) {
   WgPlan p;
   const int Cin = in.channels();
   if (!plan_wgrad<T>(B, H, W, Cin, Cout, p, in.Ca)) {
@@ -1106,12 +1112,17 @@ int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, f
 #undef WG_LAUNCH
   MIS_CHECK_LAUNCH("conv3x3_wgrad_mfma_kernel");
   const int nout = 9 * Cin * Cout;
-  if (p.nsplit <= 16 || nout >= (1 << 18))
-    wgrad_reduce_kernel<1><<<cdiv(nout, 1024), 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
-  else if (p.nsplit <= 128)
-    wgrad_reduce_kernel<4><<<cdiv(nout, 256), 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
-  else
-    wgrad_reduce_kernel<32><<<cdiv(nout, 32), 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw);
+  const int nb_bias = bias.dbias ? cdiv(Cout, 32) : 0;
+  if (p.nsplit <= 16 || nout >= (1 << 18)) {
+    const int nb = cdiv(nout, 1024);
+    wgrad_reduce_kernel<1><<<nb + nb_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, nb, bias);
+  } else if (p.nsplit <= 128) {
+    const int nb = cdiv(nout, 256);
+    wgrad_reduce_kernel<4><<<nb + nb_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, nb, bias);
+  } else {
+    const int nb = cdiv(nout, 32);
+    wgrad_reduce_kernel<32><<<nb + nb_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, nb, bias);
+  }
   MIS_CHECK_LAUNCH("wgrad_reduce_kernel");
   return MIS_OK;
 }
@@ -1137,7 +1148,7 @@ bool conv3x3_wgrad_mfma_cat_supported(int dtype, int B, int H, int W, int Ca, in
 }
 
 int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, float* dw,
-                       void* workspace, hipStream_t st) {
-  if (dtype == MIS_BF16) return run_wgrad<bf16>(in, dz, B, H, W, Cout, dw, workspace, st);
-  return run_wgrad<float>(in, dz, B, H, W, Cout, dw, workspace, st);
+                       const BiasRows& bias, void* workspace, hipStream_t st) {
+  if (dtype == MIS_BF16) return run_wgrad<bf16>(in, dz, B, H, W, Cout, dw, bias, workspace, st);
+  return run_wgrad<float>(in, dz, B, H, W, Cout, dw, bias, workspace, st);
 }

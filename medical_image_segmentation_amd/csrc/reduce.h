@@ -31,6 +31,33 @@ static inline RedPlan red_plan(int64_t n_pix, int C, int V) {
   return p;
 }
 
+// out[j] = sum_i partials[i*stride + j] for the 32 columns j of block `blk` (1024 threads: 32
+// columns x 32 row lanes, double accumulators, fixed order).  `red` is [32][33] doubles of LDS.
+__device__ __forceinline__ void reduce_rows_block(const float* __restrict__ partials, int nblk, int n,
+                                                  int64_t stride, float* __restrict__ out, int blk,
+                                                  double (*red)[33]) {
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int j = blk * 32 + c;
+  double s = 0.0;
+  if (j < n) {
+    int i = r;
+    for (; i + 96 < nblk; i += 128) {
+      const float a0 = partials[(int64_t)i * stride + j], a1 = partials[(int64_t)(i + 32) * stride + j];
+      const float a2 = partials[(int64_t)(i + 64) * stride + j], a3 = partials[(int64_t)(i + 96) * stride + j];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; i < nblk; i += 32) s += (double)partials[(int64_t)i * stride + j];
+  }
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0 && j < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) t += red[k][c];
+    out[j] = (float)t;
+  }
+}
+
 // out[j] = sum_i partials[i*stride + j], j < n, i < nblk, fixed order.
 __global__ void reduce_partials_kernel(const float* __restrict__ partials, int nblk, int n, int64_t stride,
                                        float* __restrict__ out);

@@ -203,22 +203,28 @@ def conv3x3_split_raw(x, w_packed, Ca, Cb):
     return za, zb
 
 
-def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None):
+def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None, bias_rows=None):
+    """dW of the conv; with `bias_rows` = (rows tensor [n, Cout], n) also dbias = column sums of
+    the rows, reduced inside the same launch.  Returns dw, or (dw, dbias)."""
     B, Ca, H, W = x.shape
     Cb = x2.shape[1] if x2 is not None else 0
     Cin = Ca + Cb
     Cout = dz.shape[1]
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
     ws = workspace(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), x.device)
+    rows, n_rows, dbias = None, 0, None
+    if bias_rows is not None:
+        rows, n_rows = bias_rows
+        dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
     with _prof("conv3x3_wgrad", 18 * B * H * W * Cin * Cout,
                B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout):
         if x2 is None:
             call("mis_conv3x3_wgrad", x.data_ptr(), _p(x_ss), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout,
-                 dw.data_ptr(), ws.data_ptr(), _stream())
+                 dw.data_ptr(), _p(rows), n_rows, _p(dbias), ws.data_ptr(), _stream())
         else:
             call("mis_conv3x3_cat_wgrad", x.data_ptr(), _p(x_ss), x2.data_ptr(), _p(x2_ss), dz.data_ptr(), _dt(x),
-                 B, H, W, Ca, Cb, Cout, dw.data_ptr(), ws.data_ptr(), _stream())
-    return dw
+                 B, H, W, Ca, Cb, Cout, dw.data_ptr(), _p(rows), n_rows, _p(dbias), ws.data_ptr(), _stream())
+    return dw if bias_rows is None else (dw, dbias)
 
 
 def channel_sum_raw(x):
@@ -340,10 +346,22 @@ class ConvBnReluFn(torch.autograd.Function):
         proj = sums if ctx.training else torch.zeros_like(sums)
         dz = torch.empty_like(z)
         want_db = ctx.has_bias and ctx.needs_input_grad[5]
-        dbias = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_db else None
+        want_dw = ctx.needs_input_grad[4]
+        # The conv-bias gradient (sum of dz) leaves this kernel as per-workgroup rows.  When a weight
+        # gradient follows, its reduction launch sums them too (`rows` gets a buffer of its own: the
+        # shared workspace is overwritten by the weight-gradient slabs); else they are reduced here.
+        dbias = rows = None
+        dz_ws = ws
+        if want_db and want_dw:
+            n_rows = query("mis_bn_relu_bwd_dz_rows", _dt(x), n_pix, Cout)
+            rows = torch.empty((n_rows, Cout), dtype=torch.float32, device=x.device)
+            dz_ws = rows
+        elif want_db:
+            dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
         with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
             call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
-                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(), _p(dbias), ws.data_ptr(), st)
+                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
+                 rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
         dx = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
             wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
@@ -351,7 +369,11 @@ class ConvBnReluFn(torch.autograd.Function):
                 dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
             else:
                 dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
-        dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss) if ctx.needs_input_grad[4] else None
+        dw = None
+        if rows is not None:
+            dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows))
+        elif want_dw:
+            dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss)
         return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
