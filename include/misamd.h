@@ -164,6 +164,26 @@ int mis_set_conv_path(int mode);
 /* starts with mis_conv3x3_stats_rows(...) rows of partial sums [rows][2][Cout]   */
 /* for mis_bn_finalize to reduce (one launch fewer per layer).                    */
 size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+/* Both images of MANY weight tensors in ONE launch (the parameters change every   */
+/* optimizer step, so every step re-packs all of them).  mis_pack_conv3x3_job       */
+/* (host only, no GPU work) fills one job for a weight tensor and its two          */
+/* destination images and returns the number of workgroups it needs (0: this       */
+/* tensor is not handled by the multi-tensor kernel — pack it on its own);         */
+/* first_block = sum of the counts returned for the jobs before it.  The caller     */
+/* uploads the job array and calls mis_pack_conv3x3_weights_multi with the total.   */
+typedef struct {
+  const float* w;
+  void* out_fwd;
+  void* out_t;
+  int64_t total_fwd, total_t;
+  int Cw_out, Cw_in;
+  int cpg_fwd, nt_fwd, cpg_t, nt_t;
+  int first_block, n_blocks;
+} mis_pack_job;
+int mis_pack_conv3x3_job(const float* w, int Cout_w, int Cin_w, int dtype, void* out_fwd, void* out_t, int first_block,
+                         mis_pack_job* job);
+int mis_pack_conv3x3_weights_multi(const mis_pack_job* jobs, int n_jobs, int total_blocks, int dtype,
+                                   mis_stream_t stream);
 int mis_conv3x3_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout);
 int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype,
                     int B, int H, int W, int Cin, int Cout,

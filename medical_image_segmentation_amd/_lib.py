@@ -38,6 +38,8 @@ PROTOTYPES = {
     "mis_set_conv_path": (_i, [_i]),
     "mis_conv3x3_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mis_conv3x3_stats_rows": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mis_pack_conv3x3_job": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mis_pack_conv3x3_weights_multi": (_i, [_vp, _i, _i, _i, _vp]),
     "mis_pack_conv3x3_weights_pair": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mis_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
@@ -67,7 +69,17 @@ PROTOTYPES = {
     "mis_slide_blend": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
 }
 
+
+
+class PackJob(C.Structure):
+    """mis_pack_job of include/misamd.h."""
+    _fields_ = [("w", _vp), ("out_fwd", _vp), ("out_t", _vp), ("total_fwd", _i64), ("total_t", _i64),
+                ("Cw_out", _i), ("Cw_in", _i), ("cpg_fwd", _i), ("nt_fwd", _i), ("cpg_t", _i), ("nt_t", _i),
+                ("first_block", _i), ("n_blocks", _i)]
+
+
 _lib = None
+PATH_EPOCH = 0        # bumped by every mis_set_conv_path call: cached operand images depend on the path
 
 
 def load():
@@ -90,6 +102,9 @@ def load():
 def call(name, *args):
     """Calls a status-returning entry point; non-zero -> RuntimeError(mis_last_error())."""
     lib = load()
+    if name == "mis_set_conv_path":
+        global PATH_EPOCH
+        PATH_EPOCH += 1
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.mis_last_error().decode("utf-8", "replace")

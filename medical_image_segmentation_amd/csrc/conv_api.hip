@@ -58,6 +58,22 @@ int mis_pack_conv3x3_weights_pair(const float* w, int Cout_w, int Cin_w, int dty
   return rc != MIS_OK ? rc : mis_pack_conv3x3_weights(w, Cout_w, Cin_w, 1, dtype, out_t, stream);
 }
 
+int mis_pack_conv3x3_job(const float* w, int Cout_w, int Cin_w, int dtype, void* out_fwd, void* out_t, int first_block,
+                         mis_pack_job* job) {
+  if (!w || !out_fwd || !out_t || !job || Cout_w < 1 || Cin_w < 1 || first_block < 0 ||
+      (dtype != MIS_F32 && dtype != MIS_BF16))
+    return 0;
+  if (!(use_mfma(dtype, Cin_w, Cout_w) && use_mfma(dtype, Cout_w, Cin_w))) return 0;
+  return conv3x3_mfma_pack_job(w, Cout_w, Cin_w, dtype, out_fwd, out_t, first_block, job);
+}
+
+int mis_pack_conv3x3_weights_multi(const mis_pack_job* jobs, int n_jobs, int total_blocks, int dtype,
+                                   mis_stream_t stream) {
+  MIS_REQUIRE(jobs && n_jobs >= 1 && total_blocks >= 1, "pack_conv3x3_weights_multi: bad arguments");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "pack_conv3x3_weights_multi: bad dtype %d", dtype);
+  return conv3x3_mfma_pack_multi(jobs, n_jobs, total_blocks, dtype, (hipStream_t)stream);
+}
+
 int mis_conv3x3_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout) {
   if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
   return use_mfma(dtype, Cin, Cout) ? conv3x3_mfma_stats_rows(dtype, B, H, W, Cin, Cout)

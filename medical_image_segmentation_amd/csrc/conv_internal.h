@@ -45,6 +45,10 @@ size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
 // both images (forward and transposed = data-gradient operand) of one weight tensor in one launch
 int conv3x3_mfma_pack_pair(const float* w, int Cw_out, int Cw_in, int dtype, void* out_fwd, void* out_t, hipStream_t st);
+// several weight tensors, both images each, in one launch (jobs: device array)
+int conv3x3_mfma_pack_job(const float* w, int Cw_out, int Cw_in, int dtype, void* out_fwd, void* out_t,
+                          int first_block, mis_pack_job* job);
+int conv3x3_mfma_pack_multi(const mis_pack_job* jobs_dev, int n_jobs, int total_blocks, int dtype, hipStream_t st);
 bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
 size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
 bool conv3x3_wgrad_mfma_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout);

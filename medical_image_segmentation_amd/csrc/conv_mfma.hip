@@ -94,34 +94,61 @@ __device__ __forceinline__ int halo_addr(int p, int cg) { return p * halo_pstrid
 // W[cout = 16n + (l&15)][k-group 4*step + (l>>4)], group -> (tap, cg) = (g / CPG, g % CPG).
 // One launch packs one image, or (total2 > 0) both: elements [0, total) of the `transposed`
 // image into out, then elements of the other orientation into out2.
+// element i of a packed image: [chunk][step][n-tile][lane][G]
+template <typename T>
+__device__ __forceinline__ T pack_elem(const float* __restrict__ w, int Cw_out, int Cw_in, int tr, int cpg, int ntt,
+                                       int64_t i64) {
+  constexpr int G = Mf<T>::G;
+  const int NS = (9 * cpg + 3) / 4;
+  const int Cout = tr ? Cw_in : Cw_out;     // channels the conv produces
+  const unsigned i = (unsigned)i64;         // an image has < 2^31 elements (checked where it is sized)
+  const int j = (int)(i % G);
+  const int l = (int)((i / G) % 64);
+  const unsigned q = i / (G * 64);          // (chunk, step, n-tile)
+  const int n = (int)(q % (unsigned)ntt);
+  const unsigned q2 = q / (unsigned)ntt;
+  const int s = (int)(q2 % (unsigned)NS);
+  const int c = (int)(q2 / (unsigned)NS);
+  const int g = 4 * s + (l >> 4);
+  const int tap = g / cpg, cg = g % cpg;
+  const int co = 16 * n + (l & 15);
+  const int ci = (c * cpg + cg) * G + j;
+  float v = 0.f;
+  if (tap < 9 && co < Cout) {
+    if (!tr) v = w[((int64_t)co * Cw_in + ci) * 9 + tap];
+    else v = w[((int64_t)ci * Cw_in + co) * 9 + (8 - tap)];
+  }
+  return from_f32<T>(v);
+}
+
 template <typename T>
 __global__ void pack_w3x3_frag_kernel(const float* __restrict__ w, int Cw_out, int Cw_in, int transposed,
                                       int CPG, int n_chunks, int nt_total, T* __restrict__ out, int64_t total,
                                       int CPG2, int n_chunks2, int nt_total2, T* __restrict__ out2, int64_t total2) {
-  constexpr int G = Mf<T>::G;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total + total2;
        i0 += (int64_t)gridDim.x * blockDim.x) {
     const bool second = i0 >= total;
     const int64_t i = second ? i0 - total : i0;
     const int tr = second ? !transposed : transposed;
-    const int cpg = second ? CPG2 : CPG, ntt = second ? nt_total2 : nt_total;
-    const int NS = (9 * cpg + 3) / 4;
-    const int Cout = tr ? Cw_in : Cw_out;     // channels the conv produces
-    const int j = (int)(i % G);
-    const int l = (int)((i / G) % 64);
-    const int n = (int)((i / (G * 64)) % ntt);
-    const int s = (int)((i / ((int64_t)G * 64 * ntt)) % NS);
-    const int c = (int)(i / ((int64_t)G * 64 * ntt * NS));
-    const int g = 4 * s + (l >> 4);
-    const int tap = g / cpg, cg = g % cpg;
-    const int co = 16 * n + (l & 15);
-    const int ci = (c * cpg + cg) * G + j;
-    float v = 0.f;
-    if (tap < 9 && co < Cout) {
-      if (!tr) v = w[((int64_t)co * Cw_in + ci) * 9 + tap];
-      else v = w[((int64_t)ci * Cw_in + co) * 9 + (8 - tap)];
-    }
-    (second ? out2 : out)[i] = from_f32<T>(v);
+    (second ? out2 : out)[i] = pack_elem<T>(w, Cw_out, Cw_in, tr, second ? CPG2 : CPG, second ? nt_total2 : nt_total, i);
+  }
+}
+
+// Both images of MANY weight tensors in one launch: job j owns workgroups
+// [first_block, first_block + n_blocks).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_w3x3_multi_kernel(const mis_pack_job* __restrict__ jobs, int n_jobs) {
+  int j = 0;
+  while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].first_block) j++;
+  const mis_pack_job jb = jobs[j];
+  const int64_t total = jb.total_fwd + jb.total_t;
+  for (int64_t i0 = (int64_t)((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x; i0 < total;
+       i0 += (int64_t)jb.n_blocks * 256) {
+    const bool second = i0 >= jb.total_fwd;
+    const int64_t i = second ? i0 - jb.total_fwd : i0;
+    T* out = (T*)(second ? jb.out_t : jb.out_fwd);
+    out[i] = pack_elem<T>(jb.w, jb.Cw_out, jb.Cw_in, second ? 1 : 0, second ? jb.cpg_t : jb.cpg_fwd,
+                          second ? jb.nt_t : jb.nt_fwd, i);
   }
 }
 
@@ -534,6 +561,7 @@ template <typename T>
 bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1, int Cout_a = -1) {
   constexpr int G = Mf<T>::G;
   if (Cin % G != 0 || Cout % 4 != 0 || Cin < G) return false;
+  if ((int64_t)Cin * Cout >= ((int64_t)1 << 26)) return false;      // packed image indices stay below 2^31
   const int groups = Cin / G;
   if (groups <= 4) {
     p.CPG = groups;
@@ -715,6 +743,23 @@ int conv3x3_mfma_pack_pair(const float* w, int Cw_out, int Cw_in, int dtype, voi
                                                         (float*)out_fwd, f.total, t.CPG, t.n_chunks, t.nt_total,
                                                         (float*)out_t, t.total);
   MIS_CHECK_LAUNCH("pack_w3x3_frag_kernel");
+  return MIS_OK;
+}
+
+int conv3x3_mfma_pack_job(const float* w, int Cw_out, int Cw_in, int dtype, void* out_fwd, void* out_t,
+                          int first_block, mis_pack_job* job) {
+  const PackGeom f = pack_geom(Cw_in, Cw_out, dtype), t = pack_geom(Cw_out, Cw_in, dtype);
+  int nb = cdiv(f.total + t.total, 256 * 4);          // >= 4 elements per thread
+  if (nb > 512) nb = 512;
+  *job = mis_pack_job{w, out_fwd, out_t, f.total, t.total, Cw_out, Cw_in, f.CPG, f.nt_total, t.CPG, t.nt_total,
+                      first_block, nb};
+  return nb;
+}
+
+int conv3x3_mfma_pack_multi(const mis_pack_job* jobs_dev, int n_jobs, int total_blocks, int dtype, hipStream_t st) {
+  if (dtype == MIS_BF16) pack_w3x3_multi_kernel<bf16><<<total_blocks, 256, 0, st>>>(jobs_dev, n_jobs);
+  else pack_w3x3_multi_kernel<float><<<total_blocks, 256, 0, st>>>(jobs_dev, n_jobs);
+  MIS_CHECK_LAUNCH("pack_w3x3_multi_kernel");
   return MIS_OK;
 }
 

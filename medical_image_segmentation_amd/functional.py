@@ -8,6 +8,9 @@ Layout contract: an activation is a torch tensor of logical shape [B, C, H, W]
 stored channels-last (`memory_format=torch.channels_last`), dtype float32 or
 bfloat16.  Parameters are float32 in the reference's own layouts.
 """
+import ctypes
+import weakref
+
 import torch
 
 from . import _lib
@@ -136,6 +139,80 @@ def pack_weights(w, dtype, transposed=False):
     out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     call("mis_pack_conv3x3_weights", w.data_ptr(), Co, Ci, int(transposed), _DT[dtype], out.data_ptr(), _stream())
     return out
+
+
+class WeightPacker:
+    """Operand images (forward + transposed) of a set of 3x3 conv weights, re-packed by ONE launch
+    whenever a weight changed (every optimizer step) instead of one launch per layer; in
+    inference nothing is packed after the first call.  The images live in persistent buffers and
+    are handed to `ConvBnReluFn` through `packed_for`."""
+
+    def __init__(self, weights, dtype):
+        from . import _lib
+        self.weights = [w for w in weights]
+        self.dtype = dtype
+        self.epoch = _lib.PATH_EPOCH
+        self.versions = None
+        self.images = {}
+        dev = self.weights[0].device
+        jobs, first = [], 0
+        for w in self.weights:
+            Co, Ci = w.shape[0], w.shape[1]
+            nf = query("mis_conv3x3_packed_weight_bytes", Co, Ci, 0, _DT[dtype])
+            nt = query("mis_conv3x3_packed_weight_bytes", Co, Ci, 1, _DT[dtype])
+            buf = torch.empty(align_up(nf, 256) + nt, dtype=torch.uint8, device=dev)
+            wf, wt = buf[:nf], buf[align_up(nf, 256):]
+            job = _lib.PackJob()
+            nb = query("mis_pack_conv3x3_job", w.data_ptr(), Co, Ci, _DT[dtype], wf.data_ptr(), wt.data_ptr(), first,
+                       ctypes.addressof(job))
+            if nb > 0:                       # else: this layer is packed on its own by its conv call
+                jobs.append(job)
+                first += nb
+                self.images[w.data_ptr()] = (w, wf, wt)
+        self.n_jobs, self.total_blocks = len(jobs), first
+        self.table = None
+        if jobs:
+            raw = b"".join(bytes(j) for j in jobs)
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+    def valid_for(self, weights, dtype):
+        from . import _lib
+        return (self.dtype == dtype and self.epoch == _lib.PATH_EPOCH and len(weights) == len(self.weights)
+                and all(a is b for a, b in zip(weights, self.weights))
+                and all(k == w.data_ptr() for k, (w, _, _) in self.images.items()))
+
+    def refresh(self):
+        if self.table is None:
+            return
+        versions = [w._version for w in self.weights]
+        if versions == self.versions:
+            return
+        call("mis_pack_conv3x3_weights_multi", self.table.data_ptr(), self.n_jobs, self.total_blocks,
+             _DT[self.dtype], _stream())
+        self.versions = versions
+        for w, wf, wt in self.images.values():
+            key = (id(w), self.dtype)
+            _PACKED[key] = (weakref.ref(w, lambda _r, k=key: _PACKED.pop(k, None)), w.data_ptr(), w._version, wf, wt,
+                            self.epoch)
+
+
+# (id(weight), dtype) -> (weak reference, data pointer, version, forward image, transposed image,
+# path epoch); an entry is used only for the very same tensor object, unchanged since it was packed
+_PACKED = {}
+
+
+def packed_for(weight, dtype):
+    """The current operand images of `weight` if a WeightPacker produced them, else None."""
+    from . import _lib
+    hit = _PACKED.get((id(weight), dtype))
+    if (hit is not None and hit[0]() is weight and hit[1] == weight.data_ptr() and hit[2] == weight._version
+            and hit[5] == _lib.PATH_EPOCH):
+        return hit[3], hit[4]
+    return None
+
+
+def align_up(n, a):
+    return (n + a - 1) // a * a
 
 
 def pack_weights_pair(w, dtype):
@@ -293,7 +370,10 @@ class ConvBnReluFn(torch.autograd.Function):
             raise ValueError(f"weight {tuple(weight.shape)} does not match input channels {Cin}")
         n_pix = B * H * W
         ctx.set_materialize_grads(False)
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:      # a data gradient will be asked for
+        pre = packed_for(weight, x.dtype)
+        if pre is not None:
+            wf, ctx.wt = pre
+        elif ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:    # a data gradient will be asked for
             wf, ctx.wt = pack_weights_pair(weight.detach(), x.dtype)
         else:
             wf, ctx.wt = pack_weights(weight.detach(), x.dtype), None

@@ -55,6 +55,7 @@ class UNet(nn.Module):
             raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
         down, noise = F_.PoolSkipFn.apply, F_.dropout2d_noise
         x = F_.to_act(x, self._dtype())
+        self._pack_weights(x.dtype)
         # every DoubleConv output stays lazy (z, ss): pool, upsample+concat, the next conv and the
         # 1x1 head apply its BatchNorm affine + ReLU while loading it.  `down` returns the pooled
         # tensor and the skip alias of its input, so both gradients meet in one kernel.
@@ -76,6 +77,16 @@ class UNet(nn.Module):
         y, sy = self._up(self.decoder3, y, sy, z2, s2, noise(self.decoder_dropout2, y))
         y, sy = self._up(self.decoder4, y, sy, z1, s1, None)
         return F_.Conv1x1Fn.apply(y, sy, self.out_conv.weight, self.out_conv.bias)
+
+    def _pack_weights(self, dtype):
+        """All 3x3 conv weights -> the kernels' operand images in one launch (only when a weight
+        changed since the last call)."""
+        weights = [blk[0].weight for m in self.modules() if isinstance(m, DoubleConv) for blk in (m.cbr1, m.cbr2)]
+        packer = self.__dict__.get("_mis_packer")
+        if packer is None or not packer.valid_for(weights, dtype):
+            packer = F_.WeightPacker(weights, dtype)
+            self.__dict__["_mis_packer"] = packer
+        packer.refresh()
 
     @staticmethod
     def _up(block, low, low_ss, skip, skip_ss, low_noise):

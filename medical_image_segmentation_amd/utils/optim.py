@@ -141,4 +141,11 @@ def clip_and_step(optimizer, params, max_norm=1.0):
              float(g["weight_decay"]), step, 1, norm.data_ptr() if c0 == 0 else None, st)
         for p in ps:
             optimizer.state[p]["step"] += 1
+        # the kernels wrote through raw pointers: tell autograd (and anything keyed on tensor
+        # versions, e.g. cached operand images of the weights) that these tensors changed
+        touched = list(ps) + [p.grad for p in ps]
+        for p in ps:
+            s = optimizer.state[p]
+            touched += [s["exp_avg"], s["exp_avg_sq"]]
+        torch._C._increment_version(touched)
     return norm

@@ -287,3 +287,57 @@ def test_unet_dropout_matches_oracle(dtype):
     with torch.no_grad():
         m(xh.to(DEV))
     assert torch.equal(state, torch.cuda.get_rng_state())
+
+
+def test_weight_packer_tracks_updates():
+    """One launch packs every layer's operand images; it must re-run after an optimizer step
+    (fused or torch), after load_state_dict, and not at all between two inference calls."""
+    from medical_image_segmentation_amd import functional as F_
+    from medical_image_segmentation_amd.utils.optim import clip_and_step
+    c = dict(B=2, cin=3, ncls=4, hw=32, seed=22)
+    m = build(c, torch.float32).train()
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), 5)).to(DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2)
+    launches = []
+    orig = F_.call
+
+    def counting(name, *a):
+        if name in ("mis_pack_conv3x3_weights_multi", "mis_pack_conv3x3_weights_pair", "mis_pack_conv3x3_weights"):
+            launches.append(name)
+        return orig(name, *a)
+
+    F_.call = counting
+    try:
+        y0 = m(x)
+        n_first = len(launches)
+        assert launches.count("mis_pack_conv3x3_weights_multi") == 1
+        assert n_first < 18        # layers the matrix-core kernels do not take (tiny channel counts) pack on their own
+        y0.square().mean().backward()
+        clip_and_step(opt, list(m.parameters()), 1.0)    # fused step writes through raw pointers
+        y1 = m(x)
+        assert launches.count("mis_pack_conv3x3_weights_multi") == 2
+        assert float((y1 - y0).abs().max()) > 0          # the new weights were used
+        opt.zero_grad()
+        y1.square().mean().backward()
+        torch.optim.SGD(m.parameters(), lr=1e-2).step()  # a torch optimizer
+        y2 = m(x)
+        assert launches.count("mis_pack_conv3x3_weights_multi") == 3
+        assert float((y2 - y1).abs().max()) > 0
+        # reference check of the cached images: same result as packing per layer
+        F_._PACKED.clear()
+        m.__dict__.pop("_mis_packer")
+        before = len(launches)
+        saved, F_.WeightPacker.refresh = F_.WeightPacker.refresh, lambda self: None
+        try:
+            y2b = m(x)
+        finally:
+            F_.WeightPacker.refresh = saved
+        assert len(launches) - before >= 18 and torch.equal(y2, y2b)
+        m.eval()
+        with torch.no_grad():
+            m(x)
+            before = launches.count("mis_pack_conv3x3_weights_multi")
+            m(x)
+            assert launches.count("mis_pack_conv3x3_weights_multi") == before
+    finally:
+        F_.call = orig
