@@ -38,6 +38,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // Output tile: 4 waves x MT 16-pixel row segments each, arranged as MX segments side by side
 // and MT/MX rows per wave: (16/MX) rows x (16*MX) columns.  Wider tiles read longer contiguous
 // runs of a channels-last row (fewer, larger DRAM bursts) for a slightly larger halo.
+#ifndef MIS_PRE_REL
+#define MIS_PRE_REL 0
+#endif
 #ifndef MIS_FWD_MX
 #define MIS_FWD_MX 1
 #endif
@@ -236,26 +239,31 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
 
   // tile-invariant staging state of this lane's halo elements: kept in registers, except in
   // the widest variant (no registers to spare) which recomputes it per stage
-  constexpr bool PRE = !(NT == 4 && CPG >= 3);
+  constexpr bool PRE = !(NT == 4 && CPG == 4);
+  constexpr bool PRE_REL = PRE || (MIS_PRE_REL != 0);      // the widest variant keeps only the offsets
   int tid_l = tid;        // laundered per stage when !PRE, so the recomputation is not hoisted (and spilled)
+  // (unsigned arithmetic: divisions by the compile-time halo width become a multiply-high and a shift)
   auto halo_rel = [&](int i) -> unsigned {      // byte offset of element i relative to the halo origin
-    const int v = tid_l + i * CM_THREADS, pos = v / CPG, cg = v % CPG;
-    return (unsigned)((((pos / HW_) * W + pos % HW_) * Cs + cg * G) * (int)sizeof(T));
+    const unsigned v = (unsigned)tid_l + i * CM_THREADS, pos = v / CPG, cg = v % CPG;
+    return (((pos / HW_) * (unsigned)W + pos % HW_) * (unsigned)Cs + cg * G) * (unsigned)sizeof(T);
   };
   auto halo_px = [&](int i) -> int {            // its halo column (huge for tail elements: never loaded)
-    const int v = tid_l + i * CM_THREADS;
-    return v < HALO_VECS ? (v / CPG) % HW_ : (1 << 28);
+    const unsigned v = (unsigned)tid_l + i * CM_THREADS;
+    return v < (unsigned)HALO_VECS ? (int)((v / CPG) % HW_) : (1 << 28);
   };
   auto halo_lds = [&](int i) -> int {           // its LDS slot (the dummy slot for tail elements)
-    const int v = tid_l + i * CM_THREADS;
-    return v < HALO_VECS ? halo_addr<CPG>(v / CPG, v % CPG) : HALO_BYTES - 16;
+    const unsigned v = (unsigned)tid_l + i * CM_THREADS;
+    return v < (unsigned)HALO_VECS ? (int)((v / CPG) * halo_pstride<CPG>() + (v % CPG) * 16) : HALO_BYTES - 16;
   };
-  unsigned h_rel[PRE ? HALO_IT : 1];
+  unsigned h_rel[PRE_REL ? HALO_IT : 1];
   int h_px[PRE ? HALO_IT : 1], h_lds[PRE ? HALO_IT : 1];
+  if constexpr (PRE_REL) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; i++) h_rel[i] = halo_rel(i);
+  }
   if constexpr (PRE) {
 #pragma unroll
     for (int i = 0; i < HALO_IT; i++) {
-      h_rel[i] = halo_rel(i);
       h_px[i] = halo_px(i);
       h_lds[i] = halo_lds(i);
     }
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
         (void*)(xs_ + (int64_t)(P).b * H * W * Cs), 0, img_bytes, 0x00020000);                           \
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
       const bool ok = (unsigned)(x0_ + (PRE ? h_px[PRE ? i : 0] : halo_px(i))) < (unsigned)W;            \
-      const unsigned rel_ = PRE ? h_rel[PRE ? i : 0] : halo_rel(i);                                      \
+      const unsigned rel_ = PRE_REL ? h_rel[PRE_REL ? i : 0] : halo_rel(i);                              \
       hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(ok ? base_ + rel_ : OOB), 0, 0);        \
     }                                                                                                    \
   }
@@ -326,10 +334,13 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   {                                                                                                      \
     const bool live_ = (LIVE);                                                                           \
     _Pragma("unroll") for (int i = 0; i < W_IT; i++) {                                                   \
-      const int v = tid_l + i * CM_THREADS;                                                              \
-      const int s_ = v / (NT * 64), rem = v % (NT * 64);                                                 \
-      const int off = ((((CHUNK) * NS + s_) * nt_total + n0) * 64 + rem) * 16;                           \
-      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (live_ && v < W_VECS) ? off : (int)OOB, 0, 0); \
+      /* element v = tid + i*256 of the chunk's [step][n-tile][lane] image; with 4 n-tiles a step */     \
+      /* is exactly one pass of the workgroup, so step = i and the rest is the lane's own offset */      \
+      const unsigned v = (unsigned)tid_l + i * CM_THREADS;                                               \
+      const unsigned s_ = (NT * 64 == CM_THREADS) ? (unsigned)i : v / (NT * 64);                         \
+      const unsigned rem = (NT * 64 == CM_THREADS) ? (unsigned)tid_l : v % (NT * 64);                    \
+      const unsigned off = ((((unsigned)(CHUNK) * NS + s_) * (unsigned)nt_total + (unsigned)n0) * 64 + rem) * 16; \
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (live_ && v < (unsigned)W_VECS) ? (int)off : (int)OOB, 0, 0); \
     }                                                                                                    \
   }
 #define STORE_W()                                                                                        \
