@@ -597,6 +597,13 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
     while ((Cout_a / 16) % p.NT != 0) p.NT /= 2;
     if (sizeof(T) == 2 && (Cout - Cout_a) % 8 != 0) p.NT = 1;
   }
+  {
+    // few pixels (the center layers): 64-channel slices would leave one workgroup per CU; 32-channel
+    // slices double the workgroups, and two resident per CU hide each other's staging (measured
+    // 15-25 % on those layers; with >= 2 workgroups per CU already, the wider slice is faster)
+    const int tiles = B * ((W + 15) / 16) * ((H + 15) / 16);
+    if (p.NT == 4 && tiles * (p.nt_total / 4) < 512) p.NT = 2;
+  }
   p.grid_y = p.nt_total / p.NT;
   const int MX = fwd_mx(p.NT, p.CPG), TW = 16 * MX, TH = 4 * (fwd_mt(p.NT, p.CPG) / MX), HW_ = TW + 2;
   p.tiles_x = (W + TW - 1) / TW;
