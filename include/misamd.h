@@ -285,6 +285,34 @@ int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dt
 int mis_nchw_f32_to_nhwc(const float* x, int B, int C, int H, int W, int dtype, void* y, mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
+/* AMSFN multi-scale fusion block of A_UNet (model/utils/modules.py:791-871,     */
+/* model/a_unet.py:27-30,48-51): everything that is not a convolution.            */
+/*                                                                               */
+/* nn.MaxPool2d(3, stride=1, padding=1) (modules.py:799).  argmax: uint8, same    */
+/* element count as y — the window position (0..8, row-major, first maximum)      */
+/* that supplied each output; the backward gathers dy through it.                 */
+int mis_maxpool3x3s1_fwd(const void* x, const float* x_affine, int dtype, int B, int H, int W, int C, void* y,
+                         uint8_t* argmax, mis_stream_t stream);
+int mis_maxpool3x3s1_bwd(const void* dy, const uint8_t* argmax, int dtype, int B, int H, int W, int C, void* dx,
+                         mis_stream_t stream);
+/* Fusion (modules.py:846-868): z / z_affine are HOST arrays of 4 device pointers  */
+/* (the branch outputs c1..c4, [B][HW][C] each, lazy when the affine is not NULL).  */
+/*   s[b][k*C+c] = mean_p act_k          (AdaptiveAvgPool2d(1) + cat)               */
+/*   h = relu(W1 s + b1), w = sigmoid(W2 h + b2)   (W1 [C][4C], W2 [4C][C])         */
+/*   out[b][p][c] = sum_k act_k[b][p][c] * w[b][k*C+c]                              */
+/* s [B][4C], h [B][C], w [B][4C] float32 are kept for the backward, which returns  */
+/* dact[k] = dout*w_k + ds_k/HW (gradient with respect to each branch activation)   */
+/* and the MLP parameter gradients.                                                 */
+size_t mis_amsfn_workspace_bytes(int B, int HW, int C);
+int mis_amsfn_fuse_fwd(const void* const* z, const float* const* z_affine, int dtype, int B, int HW, int C,
+                       const float* W1, const float* b1, const float* W2, const float* b2, float* s, float* h,
+                       float* w, void* out, mis_stream_t stream);
+int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const void* dout, int dtype, int B, int HW,
+                       int C, const float* W1, const float* W2, const float* s, const float* h, const float* w,
+                       void* const* dact, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
+                       mis_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
 /* Sliding-window prediction — utils/slide_predict.py:60-117.                    */
 /*                                                                               */
 /* mis_slide_gather_tiles: crops n_tiles windows out of a uint8 [H][W][C] image  */

@@ -64,6 +64,12 @@ PROTOTYPES = {
     "mis_conv1x1_bwd_workspace_bytes": (_sz, [_i64, _i, _i]),
     "mis_conv1x1_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_nchw_f32_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_maxpool3x3s1_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_maxpool3x3s1_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_amsfn_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mis_amsfn_fuse_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_amsfn_fuse_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp]),
     "mis_slide_gather_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mis_argmax_classes": (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp, _vp]),
     "mis_slide_blend": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),

@@ -1,0 +1,441 @@
+// The non-convolution parts of the AMSFN multi-scale fusion block (model/utils/modules.py:791-871
+// of the reference; used by A_UNet, model/a_unet.py:27-30,48-51):
+//
+//   * nn.MaxPool2d(kernel_size=3, stride=1, padding=1)            (modules.py:799)
+//   * nn.AdaptiveAvgPool2d(1) of the four branch outputs          (modules.py:846-856)
+//   * the squeeze MLP  conv1x1(4C->C) + ReLU + conv1x1(C->4C) + sigmoid   (modules.py:833-837,858-860)
+//   * the weighted sum of the four branches                       (modules.py:862-868)
+// and their backward passes.  The branch outputs arrive as lazy activations (conv output z +
+// BatchNorm affine): every kernel applies relu(z*scale + shift) while loading.  All reductions
+// run in a fixed order (no float atomics).  Every kernel is a streaming pass: HBM-bound.
+#include "common.h"
+#include "vec.h"
+#include "reduce.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ---- max-pool 3x3, stride 1, padding 1 ------------------------------------------------
+// Forward also records, per output element, which of the 9 window positions (row-major, first
+// maximum, NaN maximal — the scan order of torch's kernel) supplied the value; the backward is
+// then a gather: input pixel p receives dy[q] from each of the <= 9 windows q whose recorded
+// position is p.
+template <typename T, int V>
+__global__ __launch_bounds__(TPB) void maxpool3_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                           uint8_t* __restrict__ arg, int B, int H, int W, int C,
+                                                           const float* __restrict__ in_aff) {
+  extern __shared__ float aff_lds[];
+  const float* aff = nullptr;
+  if (in_aff) {
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) aff_lds[i] = in_aff[i];
+    __syncthreads();
+    aff = aff_lds;
+  }
+  const int CV = C / V;
+  const int64_t total = (int64_t)B * H * W * CV;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int xo = (int)(p % W);
+    p /= W;
+    const int yo = (int)(p % H);
+    const int b = (int)(p / H);
+    float m[V];
+    int am[V];
+    bool have = false;
+#pragma unroll
+    for (int k = 0; k < V; k++) { m[k] = 0.f; am[k] = 0; }
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const int yy = yo + dy, xx = xo + dx;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;       // padding never wins
+        float v[V];
+        vload<T, V>(x + (((int64_t)b * H + yy) * W + xx) * C + cv * V, v);
+        affine_relu_rounded<T, V>(v, aff, C, cv * V);
+        const int pos = (dy + 1) * 3 + (dx + 1);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          const bool take = !have || (v[k] > m[k]) || (v[k] != v[k] && m[k] == m[k]);
+          m[k] = take ? v[k] : m[k];
+          am[k] = take ? pos : am[k];
+        }
+        have = true;
+      }
+    }
+    vstore<T, V>(y + i * V, m);
+#pragma unroll
+    for (int k = 0; k < V; k++) arg[i * V + k] = (uint8_t)am[k];
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(TPB) void maxpool3_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ arg,
+                                                           T* __restrict__ dx, int B, int H, int W, int C) {
+  const int CV = C / V;
+  const int64_t total = (int64_t)B * H * W * CV;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int xi = (int)(p % W);
+    p /= W;
+    const int yi = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) acc[k] = 0.f;
+    // window centred at q = (yi - oy, xi - ox) sees this pixel at position (oy+1)*3 + (ox+1)
+#pragma unroll
+    for (int oy = -1; oy <= 1; oy++) {
+#pragma unroll
+      for (int ox = -1; ox <= 1; ox++) {
+        const int yq = yi - oy, xq = xi - ox;
+        if (yq < 0 || yq >= H || xq < 0 || xq >= W) continue;
+        const int64_t off = (((int64_t)b * H + yq) * W + xq) * C + cv * V;
+        float g[V];
+        vload<T, V>(dy + off, g);
+        const int pos = (oy + 1) * 3 + (ox + 1);
+#pragma unroll
+        for (int k = 0; k < V; k++) acc[k] += (arg[off + k] == pos) ? g[k] : 0.f;
+      }
+    }
+    vstore<T, V>(dx + i * V, acc);
+  }
+}
+
+// ---- the four branch tensors ----------------------------------------------------------------
+struct Branches {
+  const void* z[4];        // [B][HW][C] each
+  const float* aff[4];     // [2][C] (scale, shift) or null (plain tensor)
+};
+
+template <typename T>
+__device__ __forceinline__ float act_of(const T* z, const float* aff, int C, int64_t idx, int c) {
+  float v = to_f32(z[idx]);
+  if (aff) v = to_f32(from_f32<T>(fmaxf(v * aff[c] + aff[C + c], 0.f)));
+  return v;
+}
+
+// Global average pool of the 4 branches: s[b][k*C + c] = mean over pixels of act_k[b][p][c].
+// One workgroup per (sample, branch, 64-channel chunk): lane = channel, 4 pixel lanes per
+// channel, fixed-order tree.
+template <typename T>
+__global__ __launch_bounds__(TPB) void gap4_kernel(Branches br, int HW, int C, float* __restrict__ s) {
+  __shared__ float red[4][64];
+  const int chunks = (C + 63) / 64;
+  const int chunk = blockIdx.x % chunks, k = (blockIdx.x / chunks) % 4, b = blockIdx.x / (chunks * 4);
+  const int c = chunk * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const T* z = (const T*)br.z[k] + (int64_t)b * HW * C;
+  const float* aff = br.aff[k];
+  float acc = 0.f;
+  if (c < C)
+    for (int p = pl; p < HW; p += 4) acc += act_of<T>(z, aff, C, (int64_t)p * C + c, c);
+  red[pl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    s[(int64_t)b * 4 * C + k * C + c] = t / (float)HW;
+  }
+}
+
+// Squeeze MLP, one workgroup per sample:  h = relu(W1 s + b1) [C],  w = sigmoid(W2 h + b2) [4C].
+// W1 [C][4C], W2 [4C][C] (the 1x1 conv weights, modules.py:833-837).
+__global__ __launch_bounds__(TPB) void mlp_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W1,
+                                                      const float* __restrict__ b1, const float* __restrict__ W2,
+                                                      const float* __restrict__ b2, int C, float* __restrict__ h,
+                                                      float* __restrict__ w) {
+  extern __shared__ float sm[];              // s [4C] then h [C]
+  const int b = blockIdx.x, C4 = 4 * C;
+  float* ss = sm;
+  float* hh = sm + C4;
+  for (int i = threadIdx.x; i < C4; i += TPB) ss[i] = s[(int64_t)b * C4 + i];
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += TPB) {
+    float acc = b1[o];
+    for (int i = 0; i < C4; i++) acc += W1[(int64_t)o * C4 + i] * ss[i];
+    acc = fmaxf(acc, 0.f);
+    hh[o] = acc;
+    h[(int64_t)b * C + o] = acc;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C4; o += TPB) {
+    float acc = b2[o];
+    for (int i = 0; i < C; i++) acc += W2[(int64_t)o * C + i] * hh[i];
+    w[(int64_t)b * C4 + o] = 1.0f / (1.0f + expf(-acc));
+  }
+}
+
+// Backward, per sample: g2 = dw * w * (1-w) [4C];  dh = W2^T g2;  g1 = dh * [h > 0] [C];
+// ds = W1^T g1 [4C].  g1 and g2 are kept for the parameter gradients.
+__global__ __launch_bounds__(TPB) void mlp_bwd_sample_kernel(const float* __restrict__ dw, const float* __restrict__ w,
+                                                             const float* __restrict__ h,
+                                                             const float* __restrict__ W1,
+                                                             const float* __restrict__ W2, int C,
+                                                             float* __restrict__ g1, float* __restrict__ g2,
+                                                             float* __restrict__ ds) {
+  extern __shared__ float sm[];              // g2 [4C] then g1 [C]
+  const int b = blockIdx.x, C4 = 4 * C;
+  float* s2 = sm;
+  float* s1 = sm + C4;
+  for (int o = threadIdx.x; o < C4; o += TPB) {
+    const float y = w[(int64_t)b * C4 + o];
+    const float g = dw[(int64_t)b * C4 + o] * y * (1.0f - y);
+    s2[o] = g;
+    g2[(int64_t)b * C4 + o] = g;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += TPB) {
+    float acc = 0.f;
+    for (int o = 0; o < C4; o++) acc += W2[(int64_t)o * C + i] * s2[o];
+    acc = (h[(int64_t)b * C + i] > 0.f) ? acc : 0.f;
+    s1[i] = acc;
+    g1[(int64_t)b * C + i] = acc;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < C4; j += TPB) {
+    float acc = 0.f;
+    for (int i = 0; i < C; i++) acc += W1[(int64_t)i * C4 + j] * s1[i];
+    ds[(int64_t)b * C4 + j] = acc;
+  }
+}
+
+// Parameter gradients (sums over the batch in sample order):
+//   dW1[i][j] = sum_b g1[b][i] s[b][j],  db1[i] = sum_b g1[b][i],
+//   dW2[o][i] = sum_b g2[b][o] h[b][i],  db2[o] = sum_b g2[b][o].
+__global__ __launch_bounds__(TPB) void mlp_bwd_param_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                            const float* __restrict__ s, const float* __restrict__ h,
+                                                            int B, int C, float* __restrict__ dW1,
+                                                            float* __restrict__ db1, float* __restrict__ dW2,
+                                                            float* __restrict__ db2) {
+  const int C4 = 4 * C;
+  const int64_t nW = (int64_t)C * C4;
+  const int64_t total = 2 * nW + C + C4;
+  for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (int64_t)gridDim.x * TPB) {
+    float acc = 0.f;
+    if (e < nW) {
+      const int i = (int)(e / C4), j = (int)(e % C4);
+      for (int b = 0; b < B; b++) acc += g1[(int64_t)b * C + i] * s[(int64_t)b * C4 + j];
+      dW1[e] = acc;
+    } else if (e < 2 * nW) {
+      const int64_t f = e - nW;
+      const int o = (int)(f / C), i = (int)(f % C);
+      for (int b = 0; b < B; b++) acc += g2[(int64_t)b * C4 + o] * h[(int64_t)b * C + i];
+      dW2[f] = acc;
+    } else if (e < 2 * nW + C) {
+      const int i = (int)(e - 2 * nW);
+      for (int b = 0; b < B; b++) acc += g1[(int64_t)b * C + i];
+      db1[i] = acc;
+    } else {
+      const int o = (int)(e - 2 * nW - C);
+      for (int b = 0; b < B; b++) acc += g2[(int64_t)b * C4 + o];
+      db2[o] = acc;
+    }
+  }
+}
+
+// out[b][p][c] = sum_k act_k[b][p][c] * w[b][k*C + c]
+template <typename T>
+__global__ __launch_bounds__(TPB) void wsum_fwd_kernel(Branches br, const float* __restrict__ w, int B, int HW, int C,
+                                                       T* __restrict__ out) {
+  const int64_t total = (int64_t)B * HW * C;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((int64_t)HW * C));
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      acc += act_of<T>((const T*)br.z[k], br.aff[k], C, i, c) * w[(int64_t)b * 4 * C + k * C + c];
+    out[i] = from_f32<T>(acc);
+  }
+}
+
+// Partial sums of dw[b][k*C + c] = sum_p dout[b][p][c] * act_k[b][p][c]: workgroup (chunk, row r,
+// sample b) covers the pixels r, r + rows, ... of 64 channels and writes partial[r][b][4C].
+template <typename T>
+__global__ __launch_bounds__(TPB) void wsum_bwd_reduce_kernel(Branches br, const T* __restrict__ dout, int B, int HW,
+                                                              int C, int rows, float* __restrict__ partials) {
+  __shared__ float red[4][4][64];
+  const int chunks = (C + 63) / 64;
+  const int chunk = blockIdx.x % chunks, r = (blockIdx.x / chunks) % rows, b = blockIdx.x / (chunks * rows);
+  const int lane = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = chunk * 64 + lane;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int p = r * 4 + pl; p < HW; p += rows * 4) {
+      const int64_t idx = ((int64_t)b * HW + p) * C + c;
+      const float g = to_f32(dout[idx]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[k] += g * act_of<T>((const T*)br.z[k], br.aff[k], C, idx, c);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) red[pl][k][lane] = acc[k];
+  __syncthreads();
+  if (pl == 0 && c < C) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      partials[((int64_t)r * B + b) * 4 * C + k * C + c] =
+          (red[0][k][lane] + red[1][k][lane]) + (red[2][k][lane] + red[3][k][lane]);
+  }
+}
+
+// dact_k[b][p][c] = dout[b][p][c] * w[b][k*C + c] + ds[b][k*C + c] / HW   (weighted sum + average pool)
+struct Grads {
+  void* d[4];
+};
+template <typename T>
+__global__ __launch_bounds__(TPB) void wsum_bwd_dact_kernel(const T* __restrict__ dout, const float* __restrict__ w,
+                                                            const float* __restrict__ ds, int B, int HW, int C,
+                                                            Grads out) {
+  const int64_t total = (int64_t)B * HW * C;
+  const float inv = 1.0f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((int64_t)HW * C));
+    const float g = to_f32(dout[i]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t j = (int64_t)b * 4 * C + k * C + c;
+      ((T*)out.d[k])[i] = from_f32<T>(g * w[j] + ds[j] * inv);
+    }
+  }
+}
+
+inline int wsum_rows(int HW) {
+  int rows = HW / 256;
+  if (rows < 1) rows = 1;
+  if (rows > 64) rows = 64;
+  return rows;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mis_maxpool3x3s1_fwd(const void* x, const float* x_affine, int dtype, int B, int H, int W, int C, void* y,
+                         uint8_t* argmax, mis_stream_t stream) {
+  MIS_REQUIRE(x && y && argmax, "maxpool3x3s1_fwd: null pointer");
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1 && C <= 4096, "maxpool3x3s1_fwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = x_affine ? 2 * (size_t)C * sizeof(float) : 0;
+  const int64_t n = (int64_t)B * H * W * C;
+  if (dtype == MIS_BF16) {
+    if (pick_vec<bf16>(C, x, y) == 8)
+      maxpool3_fwd_kernel<bf16, 8><<<ew_grid(n / 8, TPB), TPB, lds, st>>>((const bf16*)x, (bf16*)y, argmax, B, H, W, C, x_affine);
+    else
+      maxpool3_fwd_kernel<bf16, 1><<<ew_grid(n, TPB), TPB, lds, st>>>((const bf16*)x, (bf16*)y, argmax, B, H, W, C, x_affine);
+  } else if (dtype == MIS_F32) {
+    if (pick_vec<float>(C, x, y) == 4)
+      maxpool3_fwd_kernel<float, 4><<<ew_grid(n / 4, TPB), TPB, lds, st>>>((const float*)x, (float*)y, argmax, B, H, W, C, x_affine);
+    else
+      maxpool3_fwd_kernel<float, 1><<<ew_grid(n, TPB), TPB, lds, st>>>((const float*)x, (float*)y, argmax, B, H, W, C, x_affine);
+  } else {
+    MIS_REQUIRE(false, "maxpool3x3s1_fwd: bad dtype %d", dtype);
+  }
+  MIS_CHECK_LAUNCH("maxpool3_fwd_kernel");
+  return MIS_OK;
+}
+
+int mis_maxpool3x3s1_bwd(const void* dy, const uint8_t* argmax, int dtype, int B, int H, int W, int C, void* dx,
+                         mis_stream_t stream) {
+  MIS_REQUIRE(dy && argmax && dx, "maxpool3x3s1_bwd: null pointer");
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, "maxpool3x3s1_bwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)B * H * W * C;
+  if (dtype == MIS_BF16) {
+    if (pick_vec<bf16>(C, dy, dx) == 8)
+      maxpool3_bwd_kernel<bf16, 8><<<ew_grid(n / 8, TPB), TPB, 0, st>>>((const bf16*)dy, argmax, (bf16*)dx, B, H, W, C);
+    else
+      maxpool3_bwd_kernel<bf16, 1><<<ew_grid(n, TPB), TPB, 0, st>>>((const bf16*)dy, argmax, (bf16*)dx, B, H, W, C);
+  } else if (dtype == MIS_F32) {
+    if (pick_vec<float>(C, dy, dx) == 4)
+      maxpool3_bwd_kernel<float, 4><<<ew_grid(n / 4, TPB), TPB, 0, st>>>((const float*)dy, argmax, (float*)dx, B, H, W, C);
+    else
+      maxpool3_bwd_kernel<float, 1><<<ew_grid(n, TPB), TPB, 0, st>>>((const float*)dy, argmax, (float*)dx, B, H, W, C);
+  } else {
+    MIS_REQUIRE(false, "maxpool3x3s1_bwd: bad dtype %d", dtype);
+  }
+  MIS_CHECK_LAUNCH("maxpool3_bwd_kernel");
+  return MIS_OK;
+}
+
+size_t mis_amsfn_workspace_bytes(int B, int HW, int C) {
+  if (B < 1 || HW < 1 || C < 1) return 0;
+  return align256((size_t)wsum_rows(HW) * B * 4 * C * sizeof(float)) + 4 * align256((size_t)B * 4 * C * sizeof(float));
+}
+
+int mis_amsfn_fuse_fwd(const void* const* z, const float* const* z_affine, int dtype, int B, int HW, int C,
+                       const float* W1, const float* b1, const float* W2, const float* b2, float* s, float* h,
+                       float* w, void* out, mis_stream_t stream) {
+  MIS_REQUIRE(z && z_affine && W1 && b1 && W2 && b2 && s && h && w && out, "amsfn_fuse_fwd: null pointer");
+  MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 1 && C <= 2048, "amsfn_fuse_fwd: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "amsfn_fuse_fwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  Branches br;
+  for (int k = 0; k < 4; k++) {
+    MIS_REQUIRE(z[k], "amsfn_fuse_fwd: null branch %d", k);
+    br.z[k] = z[k];
+    br.aff[k] = z_affine[k];
+  }
+  const int chunks = (C + 63) / 64;
+  const int64_t n = (int64_t)B * HW * C;
+  if (dtype == MIS_BF16) gap4_kernel<bf16><<<B * 4 * chunks, TPB, 0, st>>>(br, HW, C, s);
+  else gap4_kernel<float><<<B * 4 * chunks, TPB, 0, st>>>(br, HW, C, s);
+  MIS_CHECK_LAUNCH("gap4_kernel");
+  mlp_fwd_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(s, W1, b1, W2, b2, C, h, w);
+  MIS_CHECK_LAUNCH("mlp_fwd_kernel");
+  if (dtype == MIS_BF16) wsum_fwd_kernel<bf16><<<ew_grid(n, TPB), TPB, 0, st>>>(br, w, B, HW, C, (bf16*)out);
+  else wsum_fwd_kernel<float><<<ew_grid(n, TPB), TPB, 0, st>>>(br, w, B, HW, C, (float*)out);
+  MIS_CHECK_LAUNCH("wsum_fwd_kernel");
+  return MIS_OK;
+}
+
+int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const void* dout, int dtype, int B, int HW,
+                       int C, const float* W1, const float* W2, const float* s, const float* h, const float* w,
+                       void* const* dact, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
+                       mis_stream_t stream) {
+  MIS_REQUIRE(z && z_affine && dout && W1 && W2 && s && h && w && dact && dW1 && db1 && dW2 && db2 && workspace,
+              "amsfn_fuse_bwd: null pointer");
+  MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 1 && C <= 2048, "amsfn_fuse_bwd: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "amsfn_fuse_bwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  Branches br;
+  Grads gr;
+  for (int k = 0; k < 4; k++) {
+    MIS_REQUIRE(z[k] && dact[k], "amsfn_fuse_bwd: null branch %d", k);
+    br.z[k] = z[k];
+    br.aff[k] = z_affine[k];
+    gr.d[k] = dact[k];
+  }
+  const int chunks = (C + 63) / 64, rows = wsum_rows(HW), C4 = 4 * C;
+  // workspace: partial rows [rows][B][4C] | dw [B][4C] | g2 [B][4C] | ds [B][4C] | g1 [B][C]
+  const size_t vec = align256((size_t)B * C4 * sizeof(float));
+  float* partials = (float*)workspace;
+  float* dw = (float*)((char*)workspace + align256((size_t)rows * B * C4 * sizeof(float)));
+  float* g2 = (float*)((char*)dw + vec);
+  float* ds = (float*)((char*)g2 + vec);
+  float* g1 = (float*)((char*)ds + vec);
+  if (dtype == MIS_BF16)
+    wsum_bwd_reduce_kernel<bf16><<<B * rows * chunks, TPB, 0, st>>>(br, (const bf16*)dout, B, HW, C, rows, partials);
+  else
+    wsum_bwd_reduce_kernel<float><<<B * rows * chunks, TPB, 0, st>>>(br, (const float*)dout, B, HW, C, rows, partials);
+  MIS_CHECK_LAUNCH("wsum_bwd_reduce_kernel");
+  launch_reduce_partials(partials, rows, B * C4, dw, st);
+  MIS_CHECK_LAUNCH("reduce_partials_kernel");
+  mlp_bwd_sample_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(dw, w, h, W1, W2, C, g1, g2, ds);
+  MIS_CHECK_LAUNCH("mlp_bwd_sample_kernel");
+  const int64_t n = (int64_t)B * HW * C;
+  if (dtype == MIS_BF16)
+    wsum_bwd_dact_kernel<bf16><<<ew_grid(n, TPB), TPB, 0, st>>>((const bf16*)dout, w, ds, B, HW, C, gr);
+  else
+    wsum_bwd_dact_kernel<float><<<ew_grid(n, TPB), TPB, 0, st>>>((const float*)dout, w, ds, B, HW, C, gr);
+  MIS_CHECK_LAUNCH("wsum_bwd_dact_kernel");
+  const int64_t np = 2 * (int64_t)C * C4 + C + C4;
+  mlp_bwd_param_kernel<<<ew_grid(np, TPB), TPB, 0, st>>>(g1, g2, s, h, B, C, dW1, db1, dW2, db2);
+  MIS_CHECK_LAUNCH("mlp_bwd_param_kernel");
+  return MIS_OK;
+}
+
+}  // extern "C"

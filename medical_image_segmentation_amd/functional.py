@@ -46,7 +46,8 @@ def _check_act(t, name="x"):
 def to_act(t, dtype=None):
     """Any [B,C,H,W] tensor -> channels-last activation of `dtype` (default: keep)."""
     dtype = dtype or t.dtype
-    if t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda and dtype in _DT and t.shape[1] > 1:
+    tracked = t.requires_grad and torch.is_grad_enabled()      # autograd must see the conversion then
+    if t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda and dtype in _DT and t.shape[1] > 1 and not tracked:
         B, Cc, H, W = t.shape
         y = torch.empty((B, Cc, H, W), dtype=dtype, device=t.device, memory_format=torch.channels_last)
         call("mis_nchw_f32_to_nhwc", t.data_ptr(), B, Cc, H, W, _DT[dtype], y.data_ptr(), _stream())
@@ -639,6 +640,118 @@ class UpsampleFn(torch.autograd.Function):
             call("mis_upsample2x_cat_bwd", dout.data_ptr(), _p(noise), _dt(dout), B, h, w, Cup, 0, dlow.data_ptr(),
                  None, _stream())
         return dlow, None, None
+
+
+# ---------------------------------------------------------------------------
+# AMSFN pieces (model/utils/modules.py:791-871)
+# ---------------------------------------------------------------------------
+def conv_bn_relu_w(x, x_ss, weight, bias, bn, training):
+    """Like `conv_bn_relu` with an explicit [Cout, Cin, 3, 3] weight / bias (any autograd tensors)."""
+    momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
+    return ConvBnReluFn.apply(x, x_ss, None, None, weight, bias, bn.weight, bn.bias, bn.running_mean,
+                              bn.running_var, bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum))
+
+
+def pointwise_as_3x3(weight):
+    """A 1x1 conv weight [Cout, Cin, 1, 1] as the 3x3 weight whose only non-zero tap is the centre:
+    the 1x1 conv runs on the matrix-core 3x3 kernels (same sums, in the same order per tap)."""
+    return torch.nn.functional.pad(weight, (1, 1, 1, 1))
+
+
+def dwconv_as_3x3(dconv, pconv):
+    """DWConv (modules.py:52-60) = pointwise(depthwise(x)): the composition is ONE dense 3x3 conv
+    with weight W[o,i,ky,kx] = P[o,i] * D[i,ky,kx] and bias P @ bd + bp (the depthwise bias is
+    added at every pixel, padding or not, so it folds into a constant).  The products are formed
+    from the parameters (a few thousand elements) with autograd attached; the activation-sized
+    work is a single pass of the matrix-core conv kernels instead of two memory-bound passes."""
+    P = pconv.weight[:, :, 0, 0]
+    W = P[:, :, None, None] * dconv.weight[:, 0][None]
+    b = pconv.bias
+    if dconv.bias is not None:
+        fold = P @ dconv.bias
+        b = fold if b is None else b + fold
+    return W, b
+
+
+class MaxPool3x3Fn(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=3, stride=1, padding=1) of a lazy or plain activation."""
+
+    @staticmethod
+    def forward(ctx, x, x_ss):
+        _check_act(x)
+        B, Cc, H, W = x.shape
+        y = torch.empty_like(x)
+        arg = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+        with _prof("maxpool3x3_fwd", 0, 2 * x.numel() * x.element_size() + x.numel()):
+            call("mis_maxpool3x3s1_fwd", x.data_ptr(), _p(x_ss), _dt(x), B, H, W, Cc, y.data_ptr(), arg.data_ptr(),
+                 _stream())
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        arg, = ctx.saved_tensors
+        B, Cc, H, W = ctx.dims
+        dy = to_act(dy)
+        dx = torch.empty_like(dy)
+        with _prof("maxpool3x3_bwd", 0, 2 * dy.numel() * dy.element_size() + 9 * dy.numel()):
+            call("mis_maxpool3x3s1_bwd", dy.data_ptr(), arg.data_ptr(), _dt(dy), B, H, W, Cc, dx.data_ptr(), _stream())
+        return dx, None
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+class AmsfnFuseFn(torch.autograd.Function):
+    """Global average pools of the four branch outputs -> squeeze MLP -> sigmoid -> weighted sum
+    (modules.py:846-868) in one autograd node: three launches forward, five backward."""
+
+    @staticmethod
+    def forward(ctx, z1, s1, z2, s2, z3, s3, z4, s4, W1, b1, W2, b2):
+        zs, sss = [z1, z2, z3, z4], [s1, s2, s3, s4]
+        for t in zs:
+            _check_act(t)
+            if t.shape != z1.shape or t.dtype != z1.dtype:
+                raise ValueError("AMSFN branches must have equal shapes and dtypes")
+        B, Cc, H, W = z1.shape
+        if W1.shape[:2] != (Cc, 4 * Cc) or W2.shape[:2] != (4 * Cc, Cc):
+            raise ValueError(f"MLP weights {tuple(W1.shape)}, {tuple(W2.shape)} do not match {Cc} channels")
+        dev = z1.device
+        W1c, W2c = W1.detach().reshape(Cc, 4 * Cc).contiguous(), W2.detach().reshape(4 * Cc, Cc).contiguous()
+        s = torch.empty((B, 4 * Cc), dtype=torch.float32, device=dev)
+        h = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+        w = torch.empty((B, 4 * Cc), dtype=torch.float32, device=dev)
+        out = torch.empty_like(z1)
+        with _prof("amsfn_fuse_fwd", 0, 5 * z1.numel() * z1.element_size() + 4 * z1.numel() * z1.element_size()):
+            call("mis_amsfn_fuse_fwd", _ptr_array(zs), _ptr_array(sss), _dt(z1), B, H * W, Cc, W1c.data_ptr(),
+                 b1.detach().contiguous().data_ptr(), W2c.data_ptr(), b2.detach().contiguous().data_ptr(),
+                 s.data_ptr(), h.data_ptr(), w.data_ptr(), out.data_ptr(), _stream())
+        ctx.save_for_backward(z1, s1, z2, s2, z3, s3, z4, s4, W1c, W2c, s, h, w)
+        ctx.shapes = (W1.shape, W2.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z1, s1, z2, s2, z3, s3, z4, s4, W1c, W2c, s, h, w = ctx.saved_tensors
+        zs, sss = [z1, z2, z3, z4], [s1, s2, s3, s4]
+        B, Cc, H, W = z1.shape
+        dev = z1.device
+        dout = to_act(dout, z1.dtype)
+        dact = [torch.empty_like(z1) for _ in range(4)]
+        dW1 = torch.empty((Cc, 4 * Cc), dtype=torch.float32, device=dev)
+        dW2 = torch.empty((4 * Cc, Cc), dtype=torch.float32, device=dev)
+        db1 = torch.empty(Cc, dtype=torch.float32, device=dev)
+        db2 = torch.empty(4 * Cc, dtype=torch.float32, device=dev)
+        ws = workspace(query("mis_amsfn_workspace_bytes", B, H * W, Cc), dev)
+        with _prof("amsfn_fuse_bwd", 0, 10 * z1.numel() * z1.element_size()):
+            call("mis_amsfn_fuse_bwd", _ptr_array(zs), _ptr_array(sss), dout.data_ptr(), _dt(z1), B, H * W, Cc,
+                 W1c.data_ptr(), W2c.data_ptr(), s.data_ptr(), h.data_ptr(), w.data_ptr(), _ptr_array(dact),
+                 dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), ws.data_ptr(), _stream())
+        s1s, s2s = ctx.shapes
+        return (dact[0], None, dact[1], None, dact[2], None, dact[3], None, dW1.reshape(s1s), db1, dW2.reshape(s2s),
+                db2)
 
 
 class Conv1x1Fn(torch.autograd.Function):

@@ -1,7 +1,8 @@
-"""DoubleConv — drop-in for the reference's model/utils/modules.py:78-116.
+"""DoubleConv, DWConv and AMSFN — drop-ins for the reference's model/utils/modules.py:78-116,
+52-77 and 791-887.
 
-Same constructor, same children (`cbr1`, `cbr2` = Sequential(conv, bn, relu)) and therefore
-the same state_dict keys; the forward runs the fused gfx950 kernels instead of ATen.
+Same constructors, same children (`cbr1`, `cbr2` = Sequential(conv, bn, relu), ...) and therefore
+the same state_dict keys; the forwards run the fused gfx950 kernels instead of ATen.
 """
 import torch.nn as nn
 
@@ -46,6 +47,81 @@ class DoubleConv(nn.Module):
 
     def forward(self, x):
         """x: [B, C, H, W] tensor on the GPU (float32 or bfloat16) -> the block's activation."""
+        z, ss = self.forward_lazy(F_.to_act(x))
+        return F_.materialize(z, ss)
+
+    def _initialize_weights(self, init_gain=0.02):
+        _init_like_reference(self)
+
+
+class DWConv(nn.Module):
+    """Depthwise kxk conv followed by a pointwise 1x1 conv (modules.py:52-60).  Holds the same two
+    nn.Conv2d children (`dconv`, `pconv`); the blocks that use it run the pair as one dense conv
+    (see functional.dwconv_as_3x3)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1):
+        super().__init__()
+        self.dconv = nn.Conv2d(in_channels, in_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                               groups=in_channels, dilation=dilation)
+        self.pconv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        _init_like_reference(self)
+
+    def composable(self):
+        d = self.dconv
+        return (d.kernel_size == (3, 3) and d.stride == (1, 1) and d.padding == (1, 1) and d.dilation == (1, 1))
+
+
+class AMSFN(nn.Module):
+    """Adaptive multi-scale fusion block (modules.py:791-871): four branches over the same input —
+    max-pool 3x3 + 1x1 conv, and one, two, three chained DWConv — each ending in BN + ReLU; their
+    global averages go through a squeeze MLP + sigmoid to one weight per (sample, branch, channel);
+    weighted sum; 1x1 conv + BN + ReLU."""
+
+    def __init__(self, in_channels, out_channels=None, mid_channels=None):
+        super().__init__()
+        if out_channels is None:
+            out_channels = in_channels
+        if mid_channels is None:
+            mid_channels = in_channels // 2
+        C, M = in_channels, mid_channels
+
+        def dw(a, b):
+            return [DWConv(a, b, kernel_size=3, padding=1), nn.BatchNorm2d(b), nn.ReLU(inplace=True)]
+
+        self.conv1x1 = nn.Sequential(nn.MaxPool2d(kernel_size=3, stride=1, padding=1),
+                                     nn.Conv2d(C, C, kernel_size=1, padding=0), nn.BatchNorm2d(C),
+                                     nn.ReLU(inplace=True))
+        self.cbr1 = nn.Sequential(*dw(C, C))
+        self.cbr2 = nn.Sequential(*dw(C, M), *dw(M, C))
+        self.cbr3 = nn.Sequential(*dw(C, M), *dw(M, M), *dw(M, C))
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.sgm = nn.Sigmoid()
+        self.mlp = nn.Sequential(nn.Conv2d(C * 4, C, kernel_size=1), nn.ReLU(inplace=True),
+                                 nn.Conv2d(C, C * 4, kernel_size=1))
+        self.final_conv = nn.Sequential(nn.Conv2d(C, out_channels, kernel_size=1, padding=0),
+                                        nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+        _init_like_reference(self)
+
+    def _dw_chain(self, seq, x, x_ss):
+        for i in range(0, len(seq), 3):
+            W, b = F_.dwconv_as_3x3(seq[i].dconv, seq[i].pconv)
+            x, x_ss = F_.conv_bn_relu_w(x, x_ss, W, b, seq[i + 1], self.training)
+        return x, x_ss
+
+    def forward_lazy(self, x, x_ss=None):
+        """(x, x_ss) lazy or plain activation -> lazy (z, ss) of the final conv."""
+        pooled = F_.MaxPool3x3Fn.apply(x, x_ss)
+        c1 = F_.conv_bn_relu_w(pooled, None, F_.pointwise_as_3x3(self.conv1x1[1].weight), self.conv1x1[1].bias,
+                               self.conv1x1[2], self.training)
+        c2 = self._dw_chain(self.cbr1, x, x_ss)
+        c3 = self._dw_chain(self.cbr2, x, x_ss)
+        c4 = self._dw_chain(self.cbr3, x, x_ss)
+        fused = F_.AmsfnFuseFn.apply(*c1, *c2, *c3, *c4, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
+                                     self.mlp[2].bias)
+        return F_.conv_bn_relu_w(fused, None, F_.pointwise_as_3x3(self.final_conv[0].weight),
+                                 self.final_conv[0].bias, self.final_conv[1], self.training)
+
+    def forward(self, x):
         z, ss = self.forward_lazy(F_.to_act(x))
         return F_.materialize(z, ss)
 

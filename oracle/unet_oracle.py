@@ -161,6 +161,89 @@ def make_state(in_channels, n_classes, base=32, seed=1, dtype=torch.float32):
     return st
 
 
+def hash_state(spec, seed, dtype=torch.float32):
+    """Deterministic state_dict for any module: `spec` = [(key, shape), ...] in state_dict order.
+    Conv weights (4-D) are kaiming-like scaled (fan_out), 1-D '.weight' (BatchNorm gamma) in
+    [0.5, 1.5], biases in [-0.2, 0.2], running_mean 0, running_var 1, num_batches_tracked 0."""
+    from .datagen import hash_normalish, hash_uniform
+    st = OrderedDict()
+    for k, (key, shape) in enumerate(spec):
+        shape = tuple(int(v) for v in shape)
+        sd = seed * 1000 + k
+        if key.endswith("num_batches_tracked"):
+            st[key] = torch.zeros((), dtype=torch.int64)
+        elif key.endswith("running_mean"):
+            st[key] = torch.zeros(shape, dtype=dtype)
+        elif key.endswith("running_var"):
+            st[key] = torch.ones(shape, dtype=dtype)
+        elif len(shape) == 4:
+            std = math.sqrt(2.0 / (shape[0] * shape[2] * shape[3]))
+            st[key] = torch.from_numpy(hash_normalish(shape, sd, std)).to(dtype)
+        elif key.endswith(".weight"):
+            st[key] = torch.from_numpy(hash_uniform(shape, sd, 0.5, 1.5)).to(dtype)
+        else:
+            st[key] = torch.from_numpy(hash_uniform(shape, sd, -0.2, 0.2)).to(dtype)
+    return st
+
+
+def _cbr(z, state, bn_prefix, training, update_stats):
+    """BatchNorm2d + ReLU with the parameters under `bn_prefix`."""
+    g, b = state[bn_prefix + ".weight"], state[bn_prefix + ".bias"]
+    if training:
+        y, mean, var = batchnorm_train(z, g, b)
+        if update_stats:
+            update_running_stats(state, bn_prefix, mean, var, z.shape[0] * z.shape[2] * z.shape[3])
+    else:
+        y = batchnorm_eval(z, g, b, state[bn_prefix + ".running_mean"], state[bn_prefix + ".running_var"])
+    return torch.relu(y)
+
+
+def dwconv(x, state, prefix):
+    """DWConv.forward — modules.py:52-60: depthwise 3x3 (padding 1, bias) then pointwise 1x1 (bias)."""
+    d = F.conv2d(x, state[prefix + ".dconv.weight"], state[prefix + ".dconv.bias"], padding=1, groups=x.shape[1])
+    return F.conv2d(d, state[prefix + ".pconv.weight"], state[prefix + ".pconv.bias"])
+
+
+def amsfn(x, state, prefix, training=True, update_stats=True):
+    """AMSFN.forward — modules.py:844-870: four branches (max-pool 3x3 + 1x1 conv; 1, 2 and 3
+    chained DWConv-BN-ReLU), global average pools -> MLP -> sigmoid gives one weight per
+    (sample, branch, channel), weighted sum, final 1x1 conv-BN-ReLU."""
+    cbr = lambda z, p: _cbr(z, state, prefix + p, training, update_stats)
+    C = x.shape[1]
+    c1 = cbr(F.conv2d(F.max_pool2d(x, 3, 1, 1), state[prefix + ".conv1x1.1.weight"],
+                      state[prefix + ".conv1x1.1.bias"]), ".conv1x1.2")
+    c2 = cbr(dwconv(x, state, prefix + ".cbr1.0"), ".cbr1.1")
+    c3 = cbr(dwconv(x, state, prefix + ".cbr2.0"), ".cbr2.1")
+    c3 = cbr(dwconv(c3, state, prefix + ".cbr2.3"), ".cbr2.4")
+    c4 = cbr(dwconv(x, state, prefix + ".cbr3.0"), ".cbr3.1")
+    c4 = cbr(dwconv(c4, state, prefix + ".cbr3.3"), ".cbr3.4")
+    c4 = cbr(dwconv(c4, state, prefix + ".cbr3.6"), ".cbr3.7")
+    s = torch.cat([c.mean(dim=(2, 3), keepdim=True) for c in (c1, c2, c3, c4)], dim=1)
+    h = torch.relu(F.conv2d(s, state[prefix + ".mlp.0.weight"], state[prefix + ".mlp.0.bias"]))
+    w = torch.sigmoid(F.conv2d(h, state[prefix + ".mlp.2.weight"], state[prefix + ".mlp.2.bias"]))
+    out = c1 * w[:, 0:C] + c2 * w[:, C:2 * C] + c3 * w[:, 2 * C:3 * C] + c4 * w[:, 3 * C:]
+    return cbr(F.conv2d(out, state[prefix + ".final_conv.0.weight"], state[prefix + ".final_conv.0.bias"]),
+               ".final_conv.1")
+
+
+def a_unet_forward(x, state, training=True, update_stats=True):
+    """A_UNet.forward with every Dropout2d at p=0 — model/a_unet.py:59-105: the U-Net with an
+    AMSFN after each DoubleConv (the skip connections take the DoubleConv outputs, the pooling
+    and upsampling take the AMSFN outputs) and a DoubleConv as the output layer."""
+    dc = lambda t, name: double_conv(t, state, name, training, update_stats)
+    ac = lambda t, name: amsfn(t, state, name, training, update_stats)
+    e1 = dc(x, "encoder1")
+    e2 = dc(maxpool2x2(ac(e1, "acpn0")), "encoder2")
+    e3 = dc(maxpool2x2(ac(e2, "acpn1")), "encoder3")
+    e4 = dc(maxpool2x2(ac(e3, "acpn2")), "encoder4")
+    c5 = dc(maxpool2x2(ac(e4, "acpn3")), "center_conv")
+    d = ac(dc(torch.cat([upsample2x_bilinear(c5), e4], dim=1), "decoder1"), "acpn5")
+    d = ac(dc(torch.cat([upsample2x_bilinear(d), e3], dim=1), "decoder2"), "acpn6")
+    d = ac(dc(torch.cat([upsample2x_bilinear(d), e2], dim=1), "decoder3"), "acpn7")
+    d = ac(dc(torch.cat([upsample2x_bilinear(d), e1], dim=1), "decoder4"), "acpn8")
+    return dc(d, "out_conv")
+
+
 PARAM_SUFFIXES = (".0.weight", ".0.bias", ".1.weight", ".1.bias")
 
 

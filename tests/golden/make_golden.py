@@ -12,9 +12,10 @@ which touches arithmetic on the path:
     not used by UNet / diceloss / Focal_Loss / Metrics / train_one_epoch /
     SlidingWindowPredictor (torchinfo, tensorboardX, thop, mamba_ssm,
     torchvision.ops, monai.losses);
-  * DoubleConv._initialize_weights is replaced by a no-op (its last `if m.bias`
-    is mis-indented and raises AttributeError on construction,
-    model/utils/modules.py:115); all weights are then loaded explicitly.
+  * DoubleConv._initialize_weights (and DWConv's, AMSFN's) is replaced by a no-op
+    (its last `if m.bias` is mis-indented and raises AttributeError on
+    construction, model/utils/modules.py:115,76,884); all weights are then loaded
+    explicitly.
 
 usage:  python tests/golden/make_golden.py  [--ref /root/reference]
 """
@@ -61,12 +62,16 @@ def import_reference(ref_root):
     sys.path.insert(0, ref_root)
     from model.utils import modules as M
     M.DoubleConv._initialize_weights = lambda self, init_gain=0.02: None
+    # the same mis-indented `if m.bias` ends DWConv's and AMSFN's initialisers (modules.py:76, 884)
+    M.DWConv._initialize_weights = lambda self, init_gain=0.02: None
+    M.AMSFN._initialize_weights = lambda self, init_gain=0.02: None
     from model.unet import UNet
+    from model.a_unet import A_UNet
     from utils.loss_fn import diceloss, Focal_Loss, IOULoss
     from utils.metrics import Metrics
     from utils.train_and_eval import train_one_epoch, evaluate
     from utils.slide_predict import SlidingWindowPredictor
-    return types.SimpleNamespace(DoubleConv=M.DoubleConv, UNet=UNet, diceloss=diceloss,
+    return types.SimpleNamespace(DoubleConv=M.DoubleConv, UNet=UNet, A_UNet=A_UNet, AMSFN=M.AMSFN, diceloss=diceloss,
                                  Focal_Loss=Focal_Loss, IOULoss=IOULoss, Metrics=Metrics,
                                  train_one_epoch=train_one_epoch, evaluate=evaluate,
                                  SlidingWindowPredictor=SlidingWindowPredictor)
@@ -372,17 +377,70 @@ def gold_slide(R, out):
         out[f"slide_pos_{h}x{w}_{win}_{s}.pads"] = np.array(pads)
 
 
+def a_unet_cases():
+    return {"aunet_a": dict(B=2, cin=3, ncls=4, base=8, hw=32, seed=41),
+            "aunet_b": dict(B=1, cin=1, ncls=5, base=16, hw=48, seed=42)}
+
+
+def gold_a_unet(R, out):
+    """A_UNet (model/a_unet.py) and a stand-alone AMSFN block: parameters from the hash generator
+    in state_dict order (oracle.hash_state), train-mode forward + Dice loss + backward."""
+    for name, c in a_unet_cases().items():
+        m = R.A_UNet(c["cin"], c["ncls"], 0, base_channels=c["base"])
+        spec = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        st = orc.hash_state(spec, c["seed"])
+        m.load_state_dict({k: v.clone() for k, v in st.items()})
+        m.train()
+        x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100))
+        t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+        names = [f"c{i}" for i in range(1, c["ncls"])]
+        logits = m(x)
+        ld = R.diceloss(names)(logits, t)
+        ld["total_loss"].backward()
+        out[f"{name}.keys"] = np.array([k for k, _ in spec])
+        out[f"{name}.shapes"] = np.array([",".join(map(str, s)) for _, s in spec])
+        out[f"{name}.logits"] = logits.detach().numpy()
+        out[f"{name}.loss"] = np.array([float(v) for v in ld.values()], dtype=np.float64)
+        params = dict(m.named_parameters())
+        out[f"{name}.grad_keys"] = np.array(list(params.keys()))
+        out[f"{name}.grad_norms"] = np.array([float(p.grad.double().norm()) for p in params.values()])
+        out[f"{name}.running_mean.acpn0.final_conv"] = m.acpn0.final_conv[1].running_mean.numpy().copy()
+        m.eval()
+        with torch.no_grad():
+            out[f"{name}.eval_logits"] = m(x).numpy()
+    # one block on its own, with input gradient
+    blk = R.AMSFN(8)
+    spec = [(k, tuple(v.shape)) for k, v in blk.state_dict().items()]
+    st = orc.hash_state(spec, 43)
+    blk.load_state_dict({k: v.clone() for k, v in st.items()})
+    blk.train()
+    x = T(np.maximum(dg.hash_normalish((2, 8, 12, 20), 143), 0)).requires_grad_(True)     # post-ReLU like input
+    gy = T(dg.hash_normalish((2, 8, 12, 20), 243))
+    y = blk(x)
+    y.backward(gy)
+    out["amsfn.keys"] = np.array([k for k, _ in spec])
+    out["amsfn.shapes"] = np.array([",".join(map(str, s)) for _, s in spec])
+    out["amsfn.y"] = y.detach().numpy()
+    out["amsfn.dx"] = x.grad.numpy()
+    for k, p in blk.named_parameters():
+        out[f"amsfn.grad.{k}"] = p.grad.numpy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="comma-separated fixture groups (default: all)")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(1)            # fixtures must not depend on thread count
     R = import_reference(args.ref)
     groups = {"double_conv": gold_double_conv, "unet": gold_unet, "pool_up": gold_pool_up,
               "loss": gold_loss, "metrics": gold_metrics, "train": gold_train, "dp": gold_dp,
-              "slide": gold_slide}
+              "slide": gold_slide, "a_unet": gold_a_unet}
+    only = [g for g in args.only.split(",") if g]
     for gname, fn in groups.items():
+        if only and gname not in only:
+            continue
         out = {}
         fn(R, out)
         path = os.path.join(HERE, f"{gname}.npz")

@@ -1,0 +1,126 @@
+"""GPU suite: the AMSFN block and A_UNet (model/a_unet.py of the reference) through the HIP path
+against the golden vectors the reference itself produced (tests/golden/a_unet.npz) and the oracle.
+
+float32 mode: block output 1e-4, input gradient 1e-3, parameter gradients 1e-3 of each tensor's
+scale; whole network: logits 1e-3 of their scale, losses 1e-5, gradient norms 5 % (a ~90-layer
+network with 2..8-channel BatchNorm layers: single ReLU-mask flips move small gradients by per
+cents).  bfloat16 mode: loss within 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from oracle import datagen as dg
+from oracle import unet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else T(np.asarray(b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def state_from_golden(g, name, seed):
+    spec = [(str(k), tuple(int(v) for v in str(s).split(",") if v)) for k, s in zip(g[f"{name}.keys"], g[f"{name}.shapes"])]
+    return orc.hash_state(spec, seed)
+
+
+def test_maxpool3x3_matches_torch():
+    from medical_image_segmentation_amd import functional as F_
+    g = torch.Generator().manual_seed(1)
+    for dtype, C in [(torch.float32, 8), (torch.bfloat16, 16), (torch.float32, 6)]:
+        x = torch.randint(-2, 3, (2, C, 9, 13), generator=g).float()          # many ties
+        gy = torch.randn(2, C, 9, 13, generator=g)
+        xd = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = F_.MaxPool3x3Fn.apply(xd, None)
+        y.backward(gy.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last))
+        xr = x.clone().requires_grad_(True)
+        yr = torch.nn.functional.max_pool2d(xr, 3, 1, 1)
+        yr.backward(gy.to(dtype).float())
+        assert torch.equal(y.float().cpu(), yr.detach())
+        assert rel_err(xd.grad, xr.grad) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+def test_amsfn_block_golden(golden):
+    from medical_image_segmentation_amd.model.utils.modules import AMSFN
+    g = golden("a_unet")
+    st = state_from_golden(g, "amsfn", 43)
+    blk = AMSFN(8)
+    assert list(blk.state_dict().keys()) == list(st.keys())
+    blk.load_state_dict(st)
+    blk = blk.to(DEV).train()
+    x = T(np.maximum(dg.hash_normalish((2, 8, 12, 20), 143), 0)).to(DEV).requires_grad_(True)
+    gy = T(dg.hash_normalish((2, 8, 12, 20), 243)).to(DEV)
+    y = blk(x)
+    y.backward(gy)
+    assert rel_err(y, g["amsfn.y"]) < 1e-4
+    assert rel_err(x.grad, g["amsfn.dx"]) < 1e-3
+    typical = max(float(np.abs(g[f"amsfn.grad.{k}"]).max()) for k, _ in blk.named_parameters())
+    for k, p in blk.named_parameters():
+        ref = g[f"amsfn.grad.{k}"]
+        if k.endswith(("pconv.bias", "dconv.bias", "conv1x1.1.bias", "final_conv.0.bias")):
+            assert float(p.grad.abs().max()) < 1e-4 * typical, k       # analytically zero under train-mode BN
+            continue
+        assert rel_err(p.grad, ref) < 1e-3, k
+
+
+@pytest.mark.parametrize("name", list(mg.a_unet_cases()))
+def test_a_unet_fp32_golden(golden, name):
+    from medical_image_segmentation_amd.model.a_unet import A_UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    g = golden("a_unet")
+    c = mg.a_unet_cases()[name]
+    st = state_from_golden(g, name, c["seed"])
+    m = A_UNet(c["cin"], c["ncls"], 0, base_channels=c["base"], compute_dtype=torch.float32)
+    assert list(m.state_dict().keys()) == list(st.keys())
+    m.load_state_dict(st)
+    m = m.to(DEV).train()
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(DEV)
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)).to(DEV)
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    logits = m(x)
+    ld = diceloss(names)(logits, t)
+    ld["total_loss"].backward()
+    assert rel_err(logits, g[f"{name}.logits"]) < 1e-3
+    np.testing.assert_allclose([float(v.detach()) for v in ld.values()], g[f"{name}.loss"], rtol=1e-5, atol=1e-5)
+    params = dict(m.named_parameters())
+    keys = [str(k) for k in g[f"{name}.grad_keys"]]
+    assert keys == list(params.keys())
+    norms = np.array([float(params[k].grad.double().norm()) for k in keys])
+    ref = g[f"{name}.grad_norms"]
+    big = ref > 1e-3 * ref.max()
+    assert np.abs(norms[big] - ref[big]).max() / ref.max() < 5e-2
+    assert rel_err(m.acpn0.final_conv[1].running_mean, g[f"{name}.running_mean.acpn0.final_conv"]) < 1e-3
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(x), g[f"{name}.eval_logits"]) < 1e-3
+
+
+def test_a_unet_bf16_and_dropout(golden):
+    from medical_image_segmentation_amd.model.a_unet import A_UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    g = golden("a_unet")
+    name = "aunet_a"
+    c = mg.a_unet_cases()[name]
+    st = state_from_golden(g, name, c["seed"])
+    m = A_UNet(c["cin"], c["ncls"], 0, base_channels=c["base"], compute_dtype=torch.bfloat16)
+    m.load_state_dict(st)
+    m = m.to(DEV).train()
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(DEV)
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)).to(DEV)
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    logits = m(x)
+    assert logits.dtype == torch.bfloat16
+    ld = diceloss(names)(logits, t)
+    ld["total_loss"].backward()
+    assert abs(float(ld["total_loss"].detach()) - g[f"{name}.loss"][-1]) < 2e-2
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    # Dropout2d active: runs, draws 7 noise tensors, stays finite
+    m2 = A_UNet(c["cin"], c["ncls"], 0.5, base_channels=c["base"], compute_dtype=torch.float32).to(DEV).train()
+    torch.manual_seed(3)
+    y = m2(x)
+    assert torch.isfinite(y).all()

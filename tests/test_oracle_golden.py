@@ -219,3 +219,62 @@ def test_slide(golden):
         pos = orc.slide_positions(h, w, win, s)
         assert np.array_equal(np.array(pos), g[f"slide_pos_{h}x{w}_{win}_{s}.positions"])
         assert len(pos) == n_tiles and len(set(pos)) == n_unique
+
+
+def _state_from_golden(g, name, seed):
+    spec = [(str(k), tuple(int(v) for v in str(s).split(",") if v)) for k, s in zip(g[f"{name}.keys"], g[f"{name}.shapes"])]
+    return orc.hash_state(spec, seed)
+
+
+def test_amsfn_block(golden):
+    """The oracle's AMSFN against the reference block (model/utils/modules.py:791-871)."""
+    g = golden("a_unet")
+    st = _state_from_golden(g, "amsfn", 43)
+    st = {"blk." + k: v.double() if v.is_floating_point() else v for k, v in st.items()}
+    pk = [k for k in st if st[k].is_floating_point() and "running" not in k]
+    for k in pk:
+        st[k].requires_grad_(True)
+    x = T(np.maximum(dg.hash_normalish((2, 8, 12, 20), 143), 0)).double().requires_grad_(True)
+    gy = T(dg.hash_normalish((2, 8, 12, 20), 243)).double()
+    y = orc.amsfn(x, st, "blk", training=True)
+    y.backward(gy)
+    close(y.detach(), g["amsfn.y"], 1e-4, 1e-5)
+    close(x.grad, g["amsfn.dx"], 1e-3, 1e-5)
+    typical = max(float(np.abs(g[f"amsfn.grad.{k[4:]}"]).max()) for k in pk)
+    for k in pk:
+        ref = g[f"amsfn.grad.{k[4:]}"]
+        # biases that feed a train-mode BatchNorm have an analytically zero gradient: round-off on both sides
+        if k.endswith(("pconv.bias", "dconv.bias", "conv1x1.1.bias", "final_conv.0.bias")):
+            assert np.abs(ref).max() < 1e-4 * typical and float(st[k].grad.abs().max()) < 1e-4 * typical
+            continue
+        scale = np.abs(ref).max() + 1e-6
+        close(st[k].grad / scale, ref / scale, 0, 2e-4)
+
+
+@pytest.mark.parametrize("name", list(mg.a_unet_cases()))
+def test_a_unet(golden, name):
+    g = golden("a_unet")
+    c = mg.a_unet_cases()[name]
+    st = _state_from_golden(g, name, c["seed"])
+    st = {k: v.double() if v.is_floating_point() else v for k, v in st.items()}
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).double()
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    keys = [str(k) for k in g[f"{name}.grad_keys"]]
+    for k in keys:
+        st[k].requires_grad_(True)
+    logits = orc.a_unet_forward(x, st, training=True)
+    ld = orc.dice_loss(logits, t, names)
+    ld["total_loss"].backward()
+    # a 90-layer float32 network against a float64 restatement: relative to the logits' scale
+    scale = float(np.abs(g[f"{name}.logits"]).max())
+    assert float(np.abs(logits.detach().numpy() - g[f"{name}.logits"]).max()) < 1e-3 * scale
+    close([float(v) for v in ld.values()], g[f"{name}.loss"], 1e-5, 1e-6)
+    norms = np.array([float(st[k].grad.norm()) for k in keys])
+    ref = g[f"{name}.grad_norms"]
+    big = ref > 1e-3 * ref.max()          # analytically-zero bias gradients are round-off on both sides
+    assert np.abs(norms[big] - ref[big]).max() / ref.max() < 2e-2
+    close(st["acpn0.final_conv.1.running_mean"].detach(), g[f"{name}.running_mean.acpn0.final_conv"], 1e-4, 1e-5)
+    with torch.no_grad():
+        ev = orc.a_unet_forward(x, st, training=False).numpy()
+        assert float(np.abs(ev - g[f"{name}.eval_logits"]).max()) < 1e-3 * float(np.abs(g[f"{name}.eval_logits"]).max())
