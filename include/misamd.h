@@ -302,11 +302,12 @@ int mis_maxpool3x3s1_bwd(const void* dy, const uint8_t* argmax, int dtype, int B
 /*   out[b][p][c] = sum_k act_k[b][p][c] * w[b][k*C+c]                              */
 /* s [B][4C], h [B][C], w [B][4C] float32 are kept for the backward, which returns  */
 /* dact[k] = dout*w_k + ds_k/HW (gradient with respect to each branch activation)   */
-/* and the MLP parameter gradients.                                                 */
+/* and the MLP parameter gradients.  C <= 256.  Both calls need the workspace of     */
+/* mis_amsfn_workspace_bytes (partial rows of the pixel reductions).                */
 size_t mis_amsfn_workspace_bytes(int B, int HW, int C);
 int mis_amsfn_fuse_fwd(const void* const* z, const float* const* z_affine, int dtype, int B, int HW, int C,
                        const float* W1, const float* b1, const float* W2, const float* b2, float* s, float* h,
-                       float* w, void* out, mis_stream_t stream);
+                       float* w, void* out, void* workspace, mis_stream_t stream);
 int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const void* dout, int dtype, int B, int HW,
                        int C, const float* W1, const float* W2, const float* s, const float* h, const float* w,
                        void* const* dact, float* dW1, float* db1, float* dW2, float* db2, void* workspace,

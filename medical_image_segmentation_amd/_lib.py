@@ -67,7 +67,7 @@ PROTOTYPES = {
     "mis_maxpool3x3s1_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mis_maxpool3x3s1_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_amsfn_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mis_amsfn_fuse_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_amsfn_fuse_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_amsfn_fuse_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp]),
     "mis_slide_gather_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),

@@ -111,32 +111,56 @@ struct Branches {
   const float* aff[4];     // [2][C] (scale, shift) or null (plain tensor)
 };
 
-template <typename T>
-__device__ __forceinline__ float act_of(const T* z, const float* aff, int C, int64_t idx, int c) {
-  float v = to_f32(z[idx]);
-  if (aff) v = to_f32(from_f32<T>(fmaxf(v * aff[c] + aff[C + c], 0.f)));
-  return v;
+// activation vector of branch k at element offset idx (channel c0..c0+V)
+template <typename T, int V>
+__device__ __forceinline__ void act_vec(const Branches& br, int k, int C, int64_t idx, int c0, float (&v)[V]) {
+  vload<T, V>((const T*)br.z[k] + idx, v);
+  const float* aff = br.aff[k];
+  if (aff) {
+#pragma unroll
+    for (int j = 0; j < V; j++) v[j] = to_f32(from_f32<T>(fmaxf(v[j] * aff[c0 + j] + aff[C + c0 + j], 0.f)));
+  }
 }
 
-// Global average pool of the 4 branches: s[b][k*C + c] = mean over pixels of act_k[b][p][c].
-// One workgroup per (sample, branch, 64-channel chunk): lane = channel, 4 pixel lanes per
-// channel, fixed-order tree.
-template <typename T>
-__global__ __launch_bounds__(TPB) void gap4_kernel(Branches br, int HW, int C, float* __restrict__ s) {
-  __shared__ float red[4][64];
-  const int chunks = (C + 63) / 64;
-  const int chunk = blockIdx.x % chunks, k = (blockIdx.x / chunks) % 4, b = blockIdx.x / (chunks * 4);
-  const int c = chunk * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-  const T* z = (const T*)br.z[k] + (int64_t)b * HW * C;
-  const float* aff = br.aff[k];
-  float acc = 0.f;
-  if (c < C)
-    for (int p = pl; p < HW; p += 4) acc += act_of<T>(z, aff, C, (int64_t)p * C + c, c);
-  red[pl][threadIdx.x & 63] = acc;
+// partials[r][b][k*C + c] = scale * sum over the pixels p = r*PL + pl, step rows*PL, of
+// act_k[b][p][c] * (g ? g[b][p][c] : 1).  With g = null and scale = 1/HW this is the global
+// average pool of the four branches (modules.py:846-856); with g = dout it is the gradient of
+// the fusion weights.  Thread = (channel vector cv, pixel lane pl); fixed-order LDS tree.
+template <typename T, int V>
+__global__ __launch_bounds__(TPB) void branch_dot_kernel(Branches br, const T* __restrict__ g, int B, int HW, int C,
+                                                         int rows, float scale, float* __restrict__ partials) {
+  extern __shared__ float red[];             // [PL][4][C]
+  const int CV = C / V, PL = TPB / CV;
+  const int r = blockIdx.x % rows, b = blockIdx.x / rows;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  float acc[4][V];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[k][j] = 0.f;
+  if (pl < PL) {
+    for (int p = r * PL + pl; p < HW; p += rows * PL) {
+      const int64_t idx = ((int64_t)b * HW + p) * C + cv * V;
+      float gv[V];
+      if (g) vload<T, V>(g + idx, gv);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float a[V];
+        act_vec<T, V>(br, k, C, idx, cv * V, a);
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[k][j] += g ? a[j] * gv[j] : a[j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < V; j++) red[(pl * 4 + k) * C + cv * V + j] = acc[k][j];
+  }
   __syncthreads();
-  if (pl == 0 && c < C) {
-    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    s[(int64_t)b * 4 * C + k * C + c] = t / (float)HW;
+  for (int e = threadIdx.x; e < 4 * C; e += TPB) {
+    float t = 0.f;
+    for (int q = 0; q < PL; q++) t += red[q * 4 * C + e];
+    partials[((int64_t)r * B + b) * 4 * C + e] = t * scale;
   }
 }
 
@@ -236,48 +260,26 @@ __global__ __launch_bounds__(TPB) void mlp_bwd_param_kernel(const float* __restr
 }
 
 // out[b][p][c] = sum_k act_k[b][p][c] * w[b][k*C + c]
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(TPB) void wsum_fwd_kernel(Branches br, const float* __restrict__ w, int B, int HW, int C,
                                                        T* __restrict__ out) {
-  const int64_t total = (int64_t)B * HW * C;
+  const int CV = C / V;
+  const int64_t total = (int64_t)B * HW * CV;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
-    const int c = (int)(i % C);
-    const int b = (int)(i / ((int64_t)HW * C));
-    float acc = 0.f;
+    const int cv = (int)(i % CV);
+    const int b = (int)(i / ((int64_t)HW * CV));
+    float acc[V];
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      acc += act_of<T>((const T*)br.z[k], br.aff[k], C, i, c) * w[(int64_t)b * 4 * C + k * C + c];
-    out[i] = from_f32<T>(acc);
-  }
-}
-
-// Partial sums of dw[b][k*C + c] = sum_p dout[b][p][c] * act_k[b][p][c]: workgroup (chunk, row r,
-// sample b) covers the pixels r, r + rows, ... of 64 channels and writes partial[r][b][4C].
-template <typename T>
-__global__ __launch_bounds__(TPB) void wsum_bwd_reduce_kernel(Branches br, const T* __restrict__ dout, int B, int HW,
-                                                              int C, int rows, float* __restrict__ partials) {
-  __shared__ float red[4][4][64];
-  const int chunks = (C + 63) / 64;
-  const int chunk = blockIdx.x % chunks, r = (blockIdx.x / chunks) % rows, b = blockIdx.x / (chunks * rows);
-  const int lane = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = chunk * 64 + lane;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < C) {
-    for (int p = r * 4 + pl; p < HW; p += rows * 4) {
-      const int64_t idx = ((int64_t)b * HW + p) * C + c;
-      const float g = to_f32(dout[idx]);
+    for (int j = 0; j < V; j++) acc[j] = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; k++) acc[k] += g * act_of<T>((const T*)br.z[k], br.aff[k], C, idx, c);
+    for (int k = 0; k < 4; k++) {
+      float a[V];
+      act_vec<T, V>(br, k, C, i * V, cv * V, a);
+      const float* wk = w + (int64_t)b * 4 * C + k * C + cv * V;
+#pragma unroll
+      for (int j = 0; j < V; j++) acc[j] += a[j] * wk[j];
     }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; k++) red[pl][k][lane] = acc[k];
-  __syncthreads();
-  if (pl == 0 && c < C) {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      partials[((int64_t)r * B + b) * 4 * C + k * C + c] =
-          (red[0][k][lane] + red[1][k][lane]) + (red[2][k][lane] + red[3][k][lane]);
+    vstore<T, V>(out + i * V, acc);
   }
 }
 
@@ -285,28 +287,36 @@ __global__ __launch_bounds__(TPB) void wsum_bwd_reduce_kernel(Branches br, const
 struct Grads {
   void* d[4];
 };
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(TPB) void wsum_bwd_dact_kernel(const T* __restrict__ dout, const float* __restrict__ w,
                                                             const float* __restrict__ ds, int B, int HW, int C,
                                                             Grads out) {
-  const int64_t total = (int64_t)B * HW * C;
+  const int CV = C / V;
+  const int64_t total = (int64_t)B * HW * CV;
   const float inv = 1.0f / (float)HW;
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
-    const int c = (int)(i % C);
-    const int b = (int)(i / ((int64_t)HW * C));
-    const float g = to_f32(dout[i]);
+    const int cv = (int)(i % CV);
+    const int b = (int)(i / ((int64_t)HW * CV));
+    float g[V];
+    vload<T, V>(dout + i * V, g);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int64_t j = (int64_t)b * 4 * C + k * C + c;
-      ((T*)out.d[k])[i] = from_f32<T>(g * w[j] + ds[j] * inv);
+      const int64_t j0 = (int64_t)b * 4 * C + k * C + cv * V;
+      float o[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) o[j] = g[j] * w[j0 + j] + ds[j0 + j] * inv;
+      vstore<T, V>((T*)out.d[k] + i * V, o);
     }
   }
 }
 
-inline int wsum_rows(int HW) {
-  int rows = HW / 256;
+// pixel rows of the two reductions: enough workgroups to fill the chip, >= 8 pixels per thread
+inline int dot_rows(int B, int HW, int C, int V) {
+  const int PL = TPB / (C / V);
+  int rows = HW / (PL * 8);
+  const int cap = (4096 + B - 1) / B;
+  if (rows > cap) rows = cap;
   if (rows < 1) rows = 1;
-  if (rows > 64) rows = 64;
   return rows;
 }
 
@@ -361,35 +371,111 @@ int mis_maxpool3x3s1_bwd(const void* dy, const uint8_t* argmax, int dtype, int B
   return MIS_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// V = full 16-byte channel vectors when C allows (and at most 256 vectors per pixel), else scalar
+template <typename T>
+inline int fuse_vec(int C, const Branches& br, const void* a, const void* b) {
+  const int N = VecOf<T>::N;
+  uintptr_t m = (uintptr_t)a | (uintptr_t)b;
+  for (int k = 0; k < 4; k++) m |= (uintptr_t)br.z[k];
+  return (C % N == 0 && C / N <= TPB && (m % 16) == 0) ? N : 1;
+}
+
+template <typename T>
+int launch_dot(const Branches& br, const void* g, int B, int HW, int C, int V, float scale, float* partials, int& rows,
+               hipStream_t st) {
+  rows = dot_rows(B, HW, C, V);
+  const size_t lds = (size_t)(TPB / (C / V)) * 4 * C * sizeof(float);
+  if (V == VecOf<T>::N)
+    branch_dot_kernel<T, VecOf<T>::N><<<B * rows, TPB, lds, st>>>(br, (const T*)g, B, HW, C, rows, scale, partials);
+  else
+    branch_dot_kernel<T, 1><<<B * rows, TPB, lds, st>>>(br, (const T*)g, B, HW, C, rows, scale, partials);
+  return 0;
+}
+
+template <typename T>
+int fuse_fwd_t(const Branches& br, int B, int HW, int C, const float* W1, const float* b1, const float* W2,
+               const float* b2, float* s, float* h, float* w, void* out, void* workspace, hipStream_t st) {
+  const int V = fuse_vec<T>(C, br, out, nullptr);
+  int rows;
+  launch_dot<T>(br, nullptr, B, HW, C, V, 1.0f / (float)HW, (float*)workspace, rows, st);
+  MIS_CHECK_LAUNCH("branch_dot_kernel");
+  launch_reduce_partials((const float*)workspace, rows, B * 4 * C, s, st);
+  MIS_CHECK_LAUNCH("reduce_partials_kernel");
+  mlp_fwd_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(s, W1, b1, W2, b2, C, h, w);
+  MIS_CHECK_LAUNCH("mlp_fwd_kernel");
+  const int64_t n = (int64_t)B * HW * C;
+  if (V == VecOf<T>::N)
+    wsum_fwd_kernel<T, VecOf<T>::N><<<ew_grid(n / V, TPB), TPB, 0, st>>>(br, w, B, HW, C, (T*)out);
+  else
+    wsum_fwd_kernel<T, 1><<<ew_grid(n, TPB), TPB, 0, st>>>(br, w, B, HW, C, (T*)out);
+  MIS_CHECK_LAUNCH("wsum_fwd_kernel");
+  return MIS_OK;
+}
+
+template <typename T>
+int fuse_bwd_t(const Branches& br, const Grads& gr, const void* dout, int B, int HW, int C, const float* W1,
+               const float* W2, const float* s, const float* h, const float* w, float* dW1, float* db1, float* dW2,
+               float* db2, void* workspace, hipStream_t st) {
+  const int C4 = 4 * C;
+  uintptr_t m = 0;
+  for (int k = 0; k < 4; k++) m |= (uintptr_t)gr.d[k];
+  const int V = fuse_vec<T>(C, br, dout, (const void*)m);
+  // workspace: partial rows [rows][B][4C] | dw [B][4C] | g2 [B][4C] | ds [B][4C] | g1 [B][C]
+  const size_t vec = align256((size_t)B * C4 * sizeof(float));
+  float* partials = (float*)workspace;
+  float* dw = (float*)((char*)workspace + align256((size_t)dot_rows(B, HW, C, V) * B * C4 * sizeof(float)));
+  float* g2 = (float*)((char*)dw + vec);
+  float* ds = (float*)((char*)g2 + vec);
+  float* g1 = (float*)((char*)ds + vec);
+  int rows;
+  launch_dot<T>(br, dout, B, HW, C, V, 1.0f, partials, rows, st);
+  MIS_CHECK_LAUNCH("branch_dot_kernel");
+  launch_reduce_partials(partials, rows, B * C4, dw, st);
+  MIS_CHECK_LAUNCH("reduce_partials_kernel");
+  mlp_bwd_sample_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(dw, w, h, W1, W2, C, g1, g2, ds);
+  MIS_CHECK_LAUNCH("mlp_bwd_sample_kernel");
+  const int64_t n = (int64_t)B * HW * C;
+  if (V == VecOf<T>::N)
+    wsum_bwd_dact_kernel<T, VecOf<T>::N><<<ew_grid(n / V, TPB), TPB, 0, st>>>((const T*)dout, w, ds, B, HW, C, gr);
+  else
+    wsum_bwd_dact_kernel<T, 1><<<ew_grid(n, TPB), TPB, 0, st>>>((const T*)dout, w, ds, B, HW, C, gr);
+  MIS_CHECK_LAUNCH("wsum_bwd_dact_kernel");
+  const int64_t np = 2 * (int64_t)C * C4 + C + C4;
+  mlp_bwd_param_kernel<<<ew_grid(np, TPB), TPB, 0, st>>>(g1, g2, s, h, B, C, dW1, db1, dW2, db2);
+  MIS_CHECK_LAUNCH("mlp_bwd_param_kernel");
+  return MIS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 size_t mis_amsfn_workspace_bytes(int B, int HW, int C) {
   if (B < 1 || HW < 1 || C < 1) return 0;
-  return align256((size_t)wsum_rows(HW) * B * 4 * C * sizeof(float)) + 4 * align256((size_t)B * 4 * C * sizeof(float));
+  // the scalar layout has the most pixel rows
+  const int rows = dot_rows(B, HW, C, 1) > dot_rows(B, HW, C, 4) ? dot_rows(B, HW, C, 1) : dot_rows(B, HW, C, 4);
+  return align256((size_t)rows * B * 4 * C * sizeof(float)) + 4 * align256((size_t)B * 4 * C * sizeof(float));
 }
 
 int mis_amsfn_fuse_fwd(const void* const* z, const float* const* z_affine, int dtype, int B, int HW, int C,
                        const float* W1, const float* b1, const float* W2, const float* b2, float* s, float* h,
-                       float* w, void* out, mis_stream_t stream) {
-  MIS_REQUIRE(z && z_affine && W1 && b1 && W2 && b2 && s && h && w && out, "amsfn_fuse_fwd: null pointer");
-  MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 1 && C <= 2048, "amsfn_fuse_fwd: bad shape");
+                       float* w, void* out, void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(z && z_affine && W1 && b1 && W2 && b2 && s && h && w && out && workspace, "amsfn_fuse_fwd: null pointer");
+  MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 1 && C <= TPB, "amsfn_fuse_fwd: need 1 <= C <= %d (C=%d)", TPB, C);
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "amsfn_fuse_fwd: bad dtype %d", dtype);
-  hipStream_t st = (hipStream_t)stream;
   Branches br;
   for (int k = 0; k < 4; k++) {
     MIS_REQUIRE(z[k], "amsfn_fuse_fwd: null branch %d", k);
     br.z[k] = z[k];
     br.aff[k] = z_affine[k];
   }
-  const int chunks = (C + 63) / 64;
-  const int64_t n = (int64_t)B * HW * C;
-  if (dtype == MIS_BF16) gap4_kernel<bf16><<<B * 4 * chunks, TPB, 0, st>>>(br, HW, C, s);
-  else gap4_kernel<float><<<B * 4 * chunks, TPB, 0, st>>>(br, HW, C, s);
-  MIS_CHECK_LAUNCH("gap4_kernel");
-  mlp_fwd_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(s, W1, b1, W2, b2, C, h, w);
-  MIS_CHECK_LAUNCH("mlp_fwd_kernel");
-  if (dtype == MIS_BF16) wsum_fwd_kernel<bf16><<<ew_grid(n, TPB), TPB, 0, st>>>(br, w, B, HW, C, (bf16*)out);
-  else wsum_fwd_kernel<float><<<ew_grid(n, TPB), TPB, 0, st>>>(br, w, B, HW, C, (float*)out);
-  MIS_CHECK_LAUNCH("wsum_fwd_kernel");
-  return MIS_OK;
+  if (dtype == MIS_BF16)
+    return fuse_fwd_t<bf16>(br, B, HW, C, W1, b1, W2, b2, s, h, w, out, workspace, (hipStream_t)stream);
+  return fuse_fwd_t<float>(br, B, HW, C, W1, b1, W2, b2, s, h, w, out, workspace, (hipStream_t)stream);
 }
 
 int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const void* dout, int dtype, int B, int HW,
@@ -398,9 +484,8 @@ int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const
                        mis_stream_t stream) {
   MIS_REQUIRE(z && z_affine && dout && W1 && W2 && s && h && w && dact && dW1 && db1 && dW2 && db2 && workspace,
               "amsfn_fuse_bwd: null pointer");
-  MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 1 && C <= 2048, "amsfn_fuse_bwd: bad shape");
+  MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 1 && C <= TPB, "amsfn_fuse_bwd: need 1 <= C <= %d (C=%d)", TPB, C);
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "amsfn_fuse_bwd: bad dtype %d", dtype);
-  hipStream_t st = (hipStream_t)stream;
   Branches br;
   Grads gr;
   for (int k = 0; k < 4; k++) {
@@ -409,33 +494,11 @@ int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const
     br.aff[k] = z_affine[k];
     gr.d[k] = dact[k];
   }
-  const int chunks = (C + 63) / 64, rows = wsum_rows(HW), C4 = 4 * C;
-  // workspace: partial rows [rows][B][4C] | dw [B][4C] | g2 [B][4C] | ds [B][4C] | g1 [B][C]
-  const size_t vec = align256((size_t)B * C4 * sizeof(float));
-  float* partials = (float*)workspace;
-  float* dw = (float*)((char*)workspace + align256((size_t)rows * B * C4 * sizeof(float)));
-  float* g2 = (float*)((char*)dw + vec);
-  float* ds = (float*)((char*)g2 + vec);
-  float* g1 = (float*)((char*)ds + vec);
   if (dtype == MIS_BF16)
-    wsum_bwd_reduce_kernel<bf16><<<B * rows * chunks, TPB, 0, st>>>(br, (const bf16*)dout, B, HW, C, rows, partials);
-  else
-    wsum_bwd_reduce_kernel<float><<<B * rows * chunks, TPB, 0, st>>>(br, (const float*)dout, B, HW, C, rows, partials);
-  MIS_CHECK_LAUNCH("wsum_bwd_reduce_kernel");
-  launch_reduce_partials(partials, rows, B * C4, dw, st);
-  MIS_CHECK_LAUNCH("reduce_partials_kernel");
-  mlp_bwd_sample_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(dw, w, h, W1, W2, C, g1, g2, ds);
-  MIS_CHECK_LAUNCH("mlp_bwd_sample_kernel");
-  const int64_t n = (int64_t)B * HW * C;
-  if (dtype == MIS_BF16)
-    wsum_bwd_dact_kernel<bf16><<<ew_grid(n, TPB), TPB, 0, st>>>((const bf16*)dout, w, ds, B, HW, C, gr);
-  else
-    wsum_bwd_dact_kernel<float><<<ew_grid(n, TPB), TPB, 0, st>>>((const float*)dout, w, ds, B, HW, C, gr);
-  MIS_CHECK_LAUNCH("wsum_bwd_dact_kernel");
-  const int64_t np = 2 * (int64_t)C * C4 + C + C4;
-  mlp_bwd_param_kernel<<<ew_grid(np, TPB), TPB, 0, st>>>(g1, g2, s, h, B, C, dW1, db1, dW2, db2);
-  MIS_CHECK_LAUNCH("mlp_bwd_param_kernel");
-  return MIS_OK;
+    return fuse_bwd_t<bf16>(br, gr, dout, B, HW, C, W1, W2, s, h, w, dW1, db1, dW2, db2, workspace,
+                            (hipStream_t)stream);
+  return fuse_bwd_t<float>(br, gr, dout, B, HW, C, W1, W2, s, h, w, dW1, db1, dW2, db2, workspace,
+                           (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -724,10 +724,11 @@ class AmsfnFuseFn(torch.autograd.Function):
         h = torch.empty((B, Cc), dtype=torch.float32, device=dev)
         w = torch.empty((B, 4 * Cc), dtype=torch.float32, device=dev)
         out = torch.empty_like(z1)
-        with _prof("amsfn_fuse_fwd", 0, 5 * z1.numel() * z1.element_size() + 4 * z1.numel() * z1.element_size()):
+        ws = workspace(query("mis_amsfn_workspace_bytes", B, H * W, Cc), dev)
+        with _prof("amsfn_fuse_fwd", 0, 9 * z1.numel() * z1.element_size()):
             call("mis_amsfn_fuse_fwd", _ptr_array(zs), _ptr_array(sss), _dt(z1), B, H * W, Cc, W1c.data_ptr(),
                  b1.detach().contiguous().data_ptr(), W2c.data_ptr(), b2.detach().contiguous().data_ptr(),
-                 s.data_ptr(), h.data_ptr(), w.data_ptr(), out.data_ptr(), _stream())
+                 s.data_ptr(), h.data_ptr(), w.data_ptr(), out.data_ptr(), ws.data_ptr(), _stream())
         ctx.save_for_backward(z1, s1, z2, s2, z3, s3, z4, s4, W1c, W2c, s, h, w)
         ctx.shapes = (W1.shape, W2.shape)
         return out
