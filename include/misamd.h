@@ -189,6 +189,19 @@ int mis_conv3x3_fwd(const void* x, const float* x_affine, const void* w_packed, 
                     int B, int H, int W, int Cin, int Cout,
                     void* z, float* stats, void* workspace, mis_stream_t stream);
 
+/* Data gradient of a conv whose INPUT was the lazy activation relu(bn(z_prev)) of   */
+/* the previous conv+BatchNorm+ReLU (the second conv of a DoubleConv,                */
+/* model/utils/modules.py:97-99): da = conv(dz, transposed weights) as               */
+/* mis_conv3x3_fwd computes it (Cin = channels of dz, Cout = channels of da), and    */
+/* in the same kernel the BatchNorm-backward sums of that previous layer,            */
+/*   bn_sums[0][c] = sum da*[y>0],  bn_sums[1][c] = sum da*[y>0]*xhat                 */
+/* (y = z_prev*scale+shift, xhat = (z_prev-mean)*rstd; prev_affine4 = [4][Cout]),     */
+/* i.e. what mis_bn_relu_bwd_reduce(z_prev, da) would compute in a pass of its own.   */
+int mis_conv3x3_dgrad_bn_sums_supported(int dtype, int B, int H, int W, int Cin, int Cout);
+int mis_conv3x3_dgrad_bn_sums(const void* dz, const void* w_packed_t, int dtype, int B, int H, int W, int Cin, int Cout,
+                              void* da, const void* z_prev, const float* prev_affine4, float* bn_sums,
+                              void* workspace, mis_stream_t stream);
+
 /* dW float32 [Cout][Cin][3][3] = sum_{b,y,x} dz[b,y,x,co] * x[b,y+ky-1,x+kx-1,ci] */
 /* (autograd of nn.Conv2d wrt its weight).  Overwrites dw.                       */
 /* Rider (dbias not NULL): dbias float32 [Cout] = column sums of bias_rows           */

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "mis_pack_conv3x3_weights_multi": (_i, [_vp, _i, _i, _i, _vp]),
     "mis_pack_conv3x3_weights_pair": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mis_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mis_conv3x3_dgrad_bn_sums_supported": (_i, [_i] * 6),
+    "mis_conv3x3_dgrad_bn_sums": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mis_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "mis_clip_adamw_workspace_bytes": (_sz, [_i]),

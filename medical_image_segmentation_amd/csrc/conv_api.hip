@@ -113,6 +113,26 @@ size_t mis_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout)
   return (m > c ? m : c) + 256;
 }
 
+int mis_conv3x3_dgrad_bn_sums_supported(int dtype, int B, int H, int W, int Cin, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
+  return (use_mfma(dtype, Cin, Cout) && conv3x3_mfma_supported(dtype, B, H, W, Cin, Cout)) ? 1 : 0;
+}
+
+int mis_conv3x3_dgrad_bn_sums(const void* dz, const void* w_packed_t, int dtype, int B, int H, int W, int Cin, int Cout,
+                              void* da, const void* z_prev, const float* prev_affine4, float* bn_sums,
+                              void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(dz && w_packed_t && da && z_prev && prev_affine4 && bn_sums && workspace,
+              "conv3x3_dgrad_bn_sums: null pointer");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_dgrad_bn_sums: bad dtype %d", dtype);
+  if (!mis_conv3x3_dgrad_bn_sums_supported(dtype, B, H, W, Cin, Cout)) {
+    mis_set_error("conv3x3_dgrad_bn_sums: shape %d -> %d not taken by the matrix-core kernels", Cin, Cout);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  return conv3x3_mfma_fwd(ConvIn{dz, nullptr, Cin, nullptr, nullptr, 0}, w_packed_t, nullptr, dtype, B, H, W,
+                          ConvOut{da, Cout, nullptr, 0}, bn_sums, workspace, (hipStream_t)stream, z_prev,
+                          prev_affine4);
+}
+
 int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W, int Cin,
                       int Cout, float* dw, const float* bias_rows, int n_bias_rows, float* dbias, void* workspace,
                       mis_stream_t stream) {

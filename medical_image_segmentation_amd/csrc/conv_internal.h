@@ -39,8 +39,12 @@ bool conv3x3_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
 bool conv3x3_mfma_cat_supported(int dtype, int Ca, int Cb, int Cout);          // two-tensor input
 bool conv3x3_mfma_split_supported(int dtype, int Cin, int Ca, int Cb);         // two-tensor output
 size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
+// bnz / bn_aff (optional, single-tensor output only): the conv is a data gradient whose output is the
+// gradient of the lazy activation relu(bn(bnz)); `stats` then receives that BatchNorm's backward sums
+// (sum dy, sum dy*xhat) instead of (sum z, sum z^2).  bn_aff: [4][Cout] = scale, shift, mean, rstd.
 int conv3x3_mfma_fwd(const ConvIn& in, const void* wp, const float* bias, int dtype, int B, int H, int W,
-                     const ConvOut& out, float* stats, void* workspace, hipStream_t st);
+                     const ConvOut& out, float* stats, void* workspace, hipStream_t st, const void* bnz = nullptr,
+                     const float* bn_aff = nullptr);
 size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
 // both images (forward and transposed = data-gradient operand) of one weight tensor in one launch

@@ -181,12 +181,13 @@ struct TilePos {
 // and want more waves in flight, the wide ones need the registers
 constexpr int fwd_min_blocks(int nt, int cpg) { return (nt == 4 || nt * cpg >= 6) ? 2 : (nt == 1 && cpg <= 2 ? 4 : 3); }
 
-template <typename T, int NT, int CPG>
+template <typename T, int NT, int CPG, bool BNS>
 __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_mfma_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ wp, const float* __restrict__ bias,
     T* __restrict__ za, T* __restrict__ zb, float* __restrict__ partials, int B, int H, int W, int Cin, int Cs,
     int n_chunks_a, int Cout, int Cout_a, int n_chunks, int nt_total, int tiles_x, int tiles_y, int n_tiles,
-    const float* __restrict__ affa, const float* __restrict__ affb) {
+    const float* __restrict__ affa, const float* __restrict__ affb, const T* __restrict__ bnz,
+    const float* __restrict__ bn_aff) {
   // Input channels [0, Cs) come from xa and — two-tensor input — [Cs, Cin) from xb (same
   // channel count, chunks n_chunks_a.. of the K loop); both tensors have pixel stride Cs.
   // Output channels [0, Cout_a) go to za and — two-tensor output — [Cout_a, Cout) to zb; a
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   uint4* wl = reinterpret_cast<uint4*>(smem + HALO_BYTES);
   float* biasl = reinterpret_cast<float*>(wl + W_VECS);         // [NT*16], zero beyond Cout
   float* aff = biasl + NT * 16;                                 // [2][Cin] (scale, shift) of a lazy input
+  float* bnt = aff + 2 * Cin;                                   // [4][NT*16] (scale, shift, mean, rstd) of bnz
   __shared__ float red[4][2][NT * 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -282,6 +284,8 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     z_rel[j] = (co < Cout) ? (unsigned)((((wid * MY) * W + col) * Cz + cl) * (int)sizeof(T)) : OOB;
   }
   const unsigned z_row = (unsigned)(W * Cz * (int)sizeof(T)), z_seg = (unsigned)(16 * Cz * (int)sizeof(T));
+  // lane offset of the accumulators' own 4 channels (n-tile 0) inside the tile: for the BatchNorm-backward sums
+  const unsigned bz_rel = (unsigned)((((wid * MY) * W + col) * Cz + n0 * 16 + 4 * kg) * (int)sizeof(T));
 
   f32x4 s1[NT], s2[NT];
 #pragma unroll
@@ -367,11 +371,46 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
         }                                                                                                \
       }                                                                                                  \
     }                                                                                                    \
-    if (partials) {                                                                                      \
+    if (partials && !BNS) {                                                                              \
       _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                   \
         _Pragma("unroll") for (int n = 0; n < NT; n++) {                                                 \
           s1[n] += acc[m][n];                                                                            \
           s2[n] += acc[m][n] * acc[m][n];                                                                \
+        }                                                                                                \
+      }                                                                                                  \
+    }                                                                                                    \
+    if constexpr (BNS) {                                                                                 \
+      /* this conv is a data gradient: its output is the gradient `da` of the lazy activation */         \
+      /* relu(bn(bnz)); accumulate that BatchNorm's backward sums (sum dy, sum dy*xhat) here, */          \
+      /* from the values as they are stored (rounded to T), instead of a separate pass over both */      \
+      const __amdgpu_buffer_rsrc_t brs_ = __builtin_amdgcn_make_buffer_rsrc(                             \
+          (void*)(bnz + (int64_t)cur.b * H * W * Cz), 0, H * W * Cz * (int)sizeof(T), 0x00020000);       \
+      const unsigned bb_ = (unsigned)(((cur.ty * TH * W) + cur.tx * TW) * Cz * (int)sizeof(T));          \
+      _Pragma("unroll") for (int n = 0; n < NT; n++) {                                                   \
+        const f32x4 sc_ = *reinterpret_cast<const f32x4*>(&bnt[0 * NT * 16 + n * 16 + 4 * kg]);          \
+        const f32x4 sh_ = *reinterpret_cast<const f32x4*>(&bnt[1 * NT * 16 + n * 16 + 4 * kg]);          \
+        const f32x4 mu_ = *reinterpret_cast<const f32x4*>(&bnt[2 * NT * 16 + n * 16 + 4 * kg]);          \
+        const f32x4 rs_ = *reinterpret_cast<const f32x4*>(&bnt[3 * NT * 16 + n * 16 + 4 * kg]);          \
+        const bool cok_ = (n0 + n) * 16 + 4 * kg < Cout;                                                 \
+        _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                 \
+          const unsigned o_ = bb_ + (unsigned)(m / MX) * z_row + (unsigned)(m % MX) * z_seg + bz_rel +   \
+                              (unsigned)(n * 16 * (int)sizeof(T));                                       \
+          const int off_ = (int)((pvm[m] && cok_) ? o_ : OOB);                                           \
+          float zv_[4];                                                                                  \
+          if constexpr (sizeof(T) == 2) {                                                                \
+            union { u32x2 u; bf16 h[4]; } q_;                                                            \
+            q_.u = __builtin_amdgcn_raw_buffer_load_b64(brs_, off_, 0, 0);                               \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) zv_[r] = to_f32(q_.h[r]);                      \
+          } else {                                                                                       \
+            union { u32x4 u; float f[4]; } q_;                                                           \
+            q_.u = __builtin_amdgcn_raw_buffer_load_b128(brs_, off_, 0, 0);                              \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) zv_[r] = q_.f[r];                              \
+          }                                                                                              \
+          _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                \
+            const float d_ = (zv_[r] * sc_[r] + sh_[r] > 0.f) ? to_f32(from_f32<T>(acc[m][n][r])) : 0.f; \
+            s1[n][r] += d_;                                                                              \
+            s2[n][r] += d_ * ((zv_[r] - mu_[r]) * rs_[r]);                                               \
+          }                                                                                              \
         }                                                                                                \
       }                                                                                                  \
     }                                                                                                    \
@@ -415,6 +454,12 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   if (affb) {
     const int Cb = Cin - Cs;
     for (int i = tid; i < 2 * Cb; i += CM_THREADS) aff[(i / Cb) * Cin + Cs + i % Cb] = affb[i];
+  }
+  if constexpr (BNS) {
+    for (int i = tid; i < 4 * NT * 16; i += CM_THREADS) {
+      const int co = n0 * 16 + i % (NT * 16);
+      bnt[i] = (co < Cout) ? bn_aff[(i / (NT * 16)) * Cout + co] : 0.f;
+    }
   }
   // this workgroup's contiguous tile range
   const int nb_ = gridDim.x, q_ = n_tiles / nb_, r_ = n_tiles % nb_;
@@ -620,7 +665,7 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
   if (gx > p.n_tiles) gx = p.n_tiles;
   p.grid_x = gx;
   p.lds = (size_t)(TH + 2) * HW_ * (p.CPG == 4 ? 96 : (p.CPG | 1) * 16) + 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
-          (size_t)p.NT * 16 * 4 + 2 * (size_t)Cin * 4;
+          (size_t)p.NT * 16 * 4 + 2 * (size_t)Cin * 4 + 4 * (size_t)p.NT * 16 * 4;
   return true;
 }
 
@@ -631,11 +676,13 @@ struct FwdArgs {
   const float* bias;
   float* partials;
   int B, H, W;
+  const void* bnz;          // BatchNorm-backward sums of relu(bn(bnz)) with the output as gradient (or null)
+  const float* bn_aff;      // its [4][Cout] (scale, shift, mean, rstd)
 };
 
 template <typename T, int NT, int CPG>
 void launch_fwd_k(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
-  auto kfn = conv3x3_mfma_kernel<T, NT, CPG>;
+  auto kfn = a.bnz ? conv3x3_mfma_kernel<T, NT, CPG, true> : conv3x3_mfma_kernel<T, NT, CPG, false>;
   if (p.lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
   const int Cin = a.in.channels(), Cout = a.out.channels();
@@ -643,7 +690,7 @@ void launch_fwd_k(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
   kfn<<<dim3(p.grid_x, p.grid_y), CM_THREADS, p.lds, st>>>(
       (const T*)a.in.xa, (const T*)a.in.xb, (const T*)a.wp, a.bias, (T*)a.out.za, (T*)a.out.zb, a.partials, a.B, a.H,
       a.W, Cin, a.in.Ca, n_chunks_a, Cout, a.out.Ca, p.n_chunks, p.nt_total, p.tiles_x, p.tiles_y, p.n_tiles,
-      a.in.affa, a.in.affb);
+      a.in.affa, a.in.affb, (const T*)a.bnz, a.bn_aff);
 }
 
 template <typename T, int NT>
@@ -658,14 +705,14 @@ void launch_fwd_cpg(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
 
 template <typename T>
 int run_fwd(const ConvIn& in, const void* wp, const float* bias, int B, int H, int W, const ConvOut& out,
-            float* stats, void* workspace, hipStream_t st) {
+            float* stats, void* workspace, hipStream_t st, const void* bnz = nullptr, const float* bn_aff = nullptr) {
   FwdPlan p;
   const int Cin = in.channels(), Cout = out.channels();
   if (!plan_fwd<T>(B, H, W, Cin, Cout, p, in.Ca, out.Ca)) {
     mis_set_error("conv3x3_mfma: unsupported shape Cin=%d+%d Cout=%d+%d", in.Ca, in.Cb, out.Ca, out.Cb);
     return MIS_ERR_UNSUPPORTED;
   }
-  FwdArgs a{in, out, wp, bias, stats ? (float*)workspace : nullptr, B, H, W};
+  FwdArgs a{in, out, wp, bias, stats ? (float*)workspace : nullptr, B, H, W, bnz, bn_aff};
   switch (p.NT) {
     case 1: launch_fwd_cpg<T, 1>(p, a, st); break;
     case 2: launch_fwd_cpg<T, 2>(p, a, st); break;
@@ -782,9 +829,10 @@ int conv3x3_mfma_pack_multi(const mis_pack_job* jobs_dev, int n_jobs, int total_
 }
 
 int conv3x3_mfma_fwd(const ConvIn& in, const void* wp, const float* bias, int dtype, int B, int H, int W,
-                     const ConvOut& out, float* stats, void* workspace, hipStream_t st) {
-  if (dtype == MIS_BF16) return run_fwd<bf16>(in, wp, bias, B, H, W, out, stats, workspace, st);
-  return run_fwd<float>(in, wp, bias, B, H, W, out, stats, workspace, st);
+                     const ConvOut& out, float* stats, void* workspace, hipStream_t st, const void* bnz,
+                     const float* bn_aff) {
+  if (dtype == MIS_BF16) return run_fwd<bf16>(in, wp, bias, B, H, W, out, stats, workspace, st, bnz, bn_aff);
+  return run_fwd<float>(in, wp, bias, B, H, W, out, stats, workspace, st, bnz, bn_aff);
 }
 
 // =====================================================================================

@@ -348,6 +348,26 @@ def _wants_bn_sums(x_ss, numel):
             and numel >= BN_SUMS_MIN_NUMEL)
 
 
+def _dgrad_with_bn_sums(dz, wd, x, x_ss):
+    """Data gradient of a conv whose input x is a lazy activation with batch statistics riding
+    along (x_ss = [scale, shift, mean, rstd]): the kernel also accumulates the BatchNorm-backward
+    sums of x's layer, and the gradient tensor carries them to that layer's backward (which then
+    skips its reduction pass).  None when the shape is not taken by the matrix-core kernels."""
+    if x_ss is None or x_ss.dim() != 2 or x_ss.shape[0] != 4:
+        return None
+    B, Cout, H, W = x.shape                 # the data gradient produces x's channels
+    Cin = dz.shape[1]
+    if not query("mis_conv3x3_dgrad_bn_sums_supported", _dt(x), B, H, W, Cin, Cout):
+        return None
+    dx = torch.empty_like(x)
+    sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+    ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Cout), x.device)
+    with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, B * H * W * (Cin + 2 * Cout) * x.element_size()):
+        call("mis_conv3x3_dgrad_bn_sums", dz.data_ptr(), wd.data_ptr(), _dt(x), B, H, W, Cin, Cout, dx.data_ptr(),
+             x.data_ptr(), x_ss.data_ptr(), sums.data_ptr(), ws.data_ptr(), _stream())
+    return attach_bn_sums(dx, sums, x)
+
+
 class ConvBnReluFn(torch.autograd.Function):
     """(x, x_ss) -> (z, ss): the activation relu(bn(conv(act(x)))) in LAZY form — the conv output z
     plus the BatchNorm affine ss = [scale, shift]; consumers apply relu(z*scale + shift) when they
@@ -447,7 +467,9 @@ class ConvBnReluFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
             wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
             if x2 is None:
-                dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
+                dx = _dgrad_with_bn_sums(dz, wd, x, x_ss) if FUSE_BN_SUMS else None
+                if dx is None:
+                    dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
             else:
                 dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
         dw = None

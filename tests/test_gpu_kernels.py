@@ -687,6 +687,54 @@ def test_bn_sums_fused_into_gradient_producer(F_, dtype, consumer):
         assert rel_err(a, b) < tol
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ch", [(8, 16, 32), (16, 64, 64), (32, 8, 16), (64, 128, 64)])
+def test_bn_sums_fused_into_data_gradient(F_, dtype, ch):
+    """DoubleConv backward: the second conv's data-gradient kernel also accumulates the first
+    BatchNorm's backward sums (its output is that layer's `da`, and z of that layer is read in
+    the epilogue); with the fusion off the first layer runs its own reduction pass.  All
+    gradients must agree between the two runs (same arithmetic, different summation order)."""
+    Ci, Cm, Co = ch
+    B, H, W = 2, 24, 40
+    from medical_image_segmentation_amd.model.utils.modules import DoubleConv
+    torch.manual_seed(5)
+    blk = DoubleConv(Ci, Co, Cm).to(DEV).train()
+    with torch.no_grad():
+        for bn in (blk.cbr1[1], blk.cbr2[1]):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    x = dg.hash_normalish((B, Ci, H, W), 1501)
+    gy = dg.hash_normalish((B, Co, H, W), 1502)
+    res, calls = [], []
+    orig = F_.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+
+    for fuse in (True, False):
+        F_.FUSE_BN_SUMS = fuse
+        F_.call = spy
+        calls.clear()
+        try:
+            blk.zero_grad()
+            xd = act(x, dtype).requires_grad_(True)
+            z, ss = blk.forward_lazy(xd)
+            z.backward(act(gy, dtype))
+        finally:
+            F_.call = orig
+            F_.FUSE_BN_SUMS = True
+        assert calls.count("mis_bn_relu_bwd_reduce") == (1 if fuse else 2)
+        assert ("mis_conv3x3_dgrad_bn_sums" in calls) == fuse
+        res.append([xd.grad.float().clone()] + [p.grad.clone() for p in blk.parameters()])
+    tol = 5e-5 if dtype == torch.float32 else 5e-3
+    names = ["dx"] + [k for k, _ in blk.named_parameters()]
+    for k, a, b in zip(names, *res):
+        if k.endswith(".0.bias"):
+            continue                     # analytically zero under train-mode BatchNorm: round-off only
+        assert rel_err(a, b) < tol, k
+
+
 # ---------------------------------------------------------------------------
 # Dropout2d folded into the Down / Up kernels (unet.py:27-42, 49-74)
 # ---------------------------------------------------------------------------
