@@ -326,6 +326,15 @@ int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const
                        void* const* dact, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
                        mis_stream_t stream);
 
+/* DWConv (modules.py:52-60) = pointwise 1x1 after depthwise 3x3 is one dense 3x3    */
+/* conv: W[o][i][3][3] = P[o][i] * D[i][3][3], b[o] = bp[o] + sum_i P[o][i]*bd[i]      */
+/* (P = pconv.weight [Cout][Cin], D = dconv.weight [Cin][9], bd/bp their biases).      */
+/* The backward maps (dW, db) of the dense conv to (dP, dD, dbd); dbp = db.            */
+int mis_dwconv_compose_fwd(const float* P, const float* D, const float* bd, const float* bp, int Cout, int Cin,
+                           float* W, float* b, mis_stream_t stream);
+int mis_dwconv_compose_bwd(const float* P, const float* D, const float* bd, const float* dW, const float* db, int Cout,
+                           int Cin, float* dP, float* dD, float* dbd, mis_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* Sliding-window prediction — utils/slide_predict.py:60-117.                    */
 /*                                                                               */

@@ -72,6 +72,8 @@ PROTOTYPES = {
     "mis_amsfn_fuse_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_amsfn_fuse_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp]),
+    "mis_dwconv_compose_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "mis_dwconv_compose_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_slide_gather_tiles": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mis_argmax_classes": (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp, _vp]),
     "mis_slide_blend": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),

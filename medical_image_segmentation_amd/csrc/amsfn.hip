@@ -320,6 +320,53 @@ inline int dot_rows(int B, int HW, int C, int V) {
   return rows;
 }
 
+// ---- DWConv = pointwise(depthwise(x)) as one dense 3x3 conv ---------------------------------
+// W[o][i][t] = P[o][i] * D[i][t],  b[o] = bp[o] + sum_i P[o][i] * bd[i]   (modules.py:52-60)
+__global__ __launch_bounds__(TPB) void dw_compose_fwd_kernel(const float* __restrict__ P, const float* __restrict__ D,
+                                                             const float* __restrict__ bd,
+                                                             const float* __restrict__ bp, int Cout, int Cin,
+                                                             float* __restrict__ W, float* __restrict__ b) {
+  const int nW = Cout * Cin * 9;
+  for (int e = blockIdx.x * TPB + threadIdx.x; e < nW + Cout; e += gridDim.x * TPB) {
+    if (e < nW) {
+      const int t = e % 9, i = (e / 9) % Cin, o = e / (9 * Cin);
+      W[e] = P[o * Cin + i] * D[i * 9 + t];
+    } else {
+      const int o = e - nW;
+      float acc = 0.f;
+      for (int i = 0; i < Cin; i++) acc += P[o * Cin + i] * bd[i];
+      b[o] = bp[o] + acc;
+    }
+  }
+}
+
+// dP[o][i] = sum_t dW[o][i][t] D[i][t] + db[o] bd[i];  dD[i][t] = sum_o dW[o][i][t] P[o][i];
+// dbd[i] = sum_o db[o] P[o][i]   (dbp = db).  Fixed summation order.
+__global__ __launch_bounds__(TPB) void dw_compose_bwd_kernel(const float* __restrict__ P, const float* __restrict__ D,
+                                                             const float* __restrict__ bd,
+                                                             const float* __restrict__ dW,
+                                                             const float* __restrict__ db, int Cout, int Cin,
+                                                             float* __restrict__ dP, float* __restrict__ dD,
+                                                             float* __restrict__ dbd) {
+  const int nP = Cout * Cin, nD = Cin * 9;
+  for (int e = blockIdx.x * TPB + threadIdx.x; e < nP + nD + Cin; e += gridDim.x * TPB) {
+    float acc = 0.f;
+    if (e < nP) {
+      const int i = e % Cin, o = e / Cin;
+      for (int t = 0; t < 9; t++) acc += dW[(o * Cin + i) * 9 + t] * D[i * 9 + t];
+      dP[e] = acc + db[o] * bd[i];
+    } else if (e < nP + nD) {
+      const int f = e - nP, t = f % 9, i = f / 9;
+      for (int o = 0; o < Cout; o++) acc += dW[(o * Cin + i) * 9 + t] * P[o * Cin + i];
+      dD[f] = acc;
+    } else {
+      const int i = e - nP - nD;
+      for (int o = 0; o < Cout; o++) acc += db[o] * P[o * Cin + i];
+      dbd[i] = acc;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -499,6 +546,26 @@ int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const
                             (hipStream_t)stream);
   return fuse_bwd_t<float>(br, gr, dout, B, HW, C, W1, W2, s, h, w, dW1, db1, dW2, db2, workspace,
                            (hipStream_t)stream);
+}
+
+int mis_dwconv_compose_fwd(const float* P, const float* D, const float* bd, const float* bp, int Cout, int Cin,
+                           float* W, float* b, mis_stream_t stream) {
+  MIS_REQUIRE(P && D && bd && bp && W && b, "dwconv_compose_fwd: null pointer");
+  MIS_REQUIRE(Cout >= 1 && Cin >= 1 && (int64_t)Cout * Cin * 9 < (1 << 30), "dwconv_compose_fwd: bad shape");
+  dw_compose_fwd_kernel<<<ew_grid((int64_t)Cout * Cin * 9 + Cout, TPB), TPB, 0, (hipStream_t)stream>>>(P, D, bd, bp, Cout,
+                                                                                                     Cin, W, b);
+  MIS_CHECK_LAUNCH("dw_compose_fwd_kernel");
+  return MIS_OK;
+}
+
+int mis_dwconv_compose_bwd(const float* P, const float* D, const float* bd, const float* dW, const float* db, int Cout,
+                           int Cin, float* dP, float* dD, float* dbd, mis_stream_t stream) {
+  MIS_REQUIRE(P && D && bd && dW && db && dP && dD && dbd, "dwconv_compose_bwd: null pointer");
+  MIS_REQUIRE(Cout >= 1 && Cin >= 1 && (int64_t)Cout * Cin * 9 < (1 << 30), "dwconv_compose_bwd: bad shape");
+  dw_compose_bwd_kernel<<<ew_grid((int64_t)Cout * Cin + Cin * 10, TPB), TPB, 0, (hipStream_t)stream>>>(
+      P, D, bd, dW, db, Cout, Cin, dP, dD, dbd);
+  MIS_CHECK_LAUNCH("dw_compose_bwd_kernel");
+  return MIS_OK;
 }
 
 }  // extern "C"
