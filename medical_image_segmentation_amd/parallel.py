@@ -19,6 +19,8 @@ class GradSync:
     def __init__(self, model, n_buckets=3, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # RCCL averages in the collective; other backends (gloo) only sum
+        self.avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         params = [p for p in model.parameters() if p.requires_grad]
         order = list(reversed(params))                       # backward order
         total = sum(p.numel() for p in order)
@@ -61,7 +63,7 @@ class GradSync:
         views = flat.split([p.numel() for p in b])
         torch._foreach_copy_(list(views), [p.grad.reshape(-1) for p in b])
         if self.world > 1:
-            self.handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if flat.is_cuda else dist.ReduceOp.SUM,
+            self.handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM,
                                                group=self.group, async_op=True)
 
     def _on_grad(self, p):
@@ -81,7 +83,7 @@ class GradSync:
             if self.handles[bi] is not None:
                 self.handles[bi].wait()
             flat = self.flat[bi]
-            if self.world > 1 and not flat.is_cuda:
+            if self.world > 1 and not self.avg_in_collective:
                 flat.div_(self.world)             # gloo has no AVG
             if self.world > 1:
                 views = flat.split([p.numel() for p in b])
