@@ -169,14 +169,18 @@ def main():
     met = _finish_metrics(metric, pending, 4) / max(len(pending), 1)
 
     roof = None
-    if not args.no_roofline and rank == 0:
-        F_.PROFILE = {}
+    if not args.no_roofline:
+        # instrumented replay: every rank runs the same 3 steps (they contain the gradient
+        # collectives), rank 0 records the per-kernel HIP events
+        if rank == 0:
+            F_.PROFILE = {}
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        roof = F_.profile_summary(PEAK_HBM_GBS, PEAK_BF16_TFLOPS, steps=3)
-        F_.PROFILE = None
-        pmc_traffic(roof["dominant"], B, S, args.dtype)
+        if rank == 0:
+            roof = F_.profile_summary(PEAK_HBM_GBS, PEAK_BF16_TFLOPS, steps=3)
+            F_.PROFILE = None
+            pmc_traffic(roof["dominant"], B, S, args.dtype)
 
     if rank == 0:
         out = {
