@@ -49,6 +49,44 @@ def _finish_metrics(Metric, pending, n_rows):
     return total
 
 
+def _device_batches(loader, device):
+    """Yields (images, masks) of each `data` of the loader (batch format data[0][0], data[0][1],
+    train_and_eval.py:72-73) already on `device`.  On a GPU the copy of batch i+1 is issued on a
+    side stream right after the work of batch i has been enqueued, so it overlaps that work (fully
+    when the loader pins its memory); the compute stream waits on the copy's event only."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        for data in loader:
+            yield data[0][0].to(dev), data[0][1].to(dev)
+        return
+    side = torch.cuda.Stream(dev)
+
+    def stage(data):
+        with torch.cuda.stream(side):
+            im = data[0][0].to(dev, non_blocking=True)
+            mk = data[0][1].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        return im, mk, ev
+
+    it = iter(loader)
+    try:
+        nxt = stage(next(it))
+    except StopIteration:
+        return
+    while nxt is not None:
+        im, mk, ev = nxt
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(ev)
+        im.record_stream(cur)
+        mk.record_stream(cur)
+        yield im, mk
+        try:
+            nxt = stage(next(it))          # runs after the consumer enqueued this batch's work
+        except StopIteration:
+            nxt = None
+
+
 def train_one_epoch(model, optimizer, epoch, train_dataloader, device, loss_fn, scaler, Metric, scheduler,
                     class_names, elnloss, l1_lambda, l2_lambda):
     model.train()
@@ -60,9 +98,7 @@ def train_one_epoch(model, optimizer, epoch, train_dataloader, device, loss_fn, 
     use_scaler = scaler is not None and scaler.is_enabled()
     params = [p for p in model.parameters() if p.requires_grad]
 
-    for data in loader:
-        images, masks = data[0][0], data[0][1]
-        images, masks = images.to(device, non_blocking=True), masks.to(device, non_blocking=True)
+    for images, masks in _device_batches(loader, device):
         optimizer.zero_grad()
         with autocast(device_type="cuda", dtype=torch.bfloat16):
             pred = model(images)
@@ -105,8 +141,7 @@ def evaluate(model, device, data_loader, loss_fn, Metric, class_names, test: boo
     pending = []
     with torch.no_grad():
         loader = tqdm(data_loader, desc="  Validating ", leave=False)
-        for data in loader:
-            images, masks = data[0][0].to(device, non_blocking=True), data[0][1].to(device, non_blocking=True)
+        for images, masks in _device_batches(loader, device):
             with autocast(device_type="cuda", dtype=torch.bfloat16):
                 pred_mask = model(images)
                 masks = masks.to(torch.int64)

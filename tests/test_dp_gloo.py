@@ -112,3 +112,15 @@ def test_finish_metrics_averages_batches(golden):
     assert np.allclose(total, M.from_counts(cm) + M.from_counts(cm[:1]))
     with pytest.raises(RuntimeError):
         _finish_metrics(M, [(cm, torch.ones(1, dtype=torch.int32))], 4)
+
+
+def test_device_batches_order_and_format():
+    """The batch iterator keeps the loader's order and the reference's batch format
+    (data[0][0] = images, data[0][1] = masks, data[1] = names) on any device."""
+    from medical_image_segmentation_amd.utils.train_and_eval import _device_batches
+    batches = [((torch.full((2, 1, 4, 4), float(i)), torch.full((2, 4, 4), i)), [f"n{i}"]) for i in range(5)]
+    got = list(_device_batches(batches, "cpu"))
+    assert len(got) == 5
+    for i, (im, mk) in enumerate(got):
+        assert float(im.mean()) == i and int(mk.max()) == i
+    assert list(_device_batches([], "cpu")) == []
