@@ -38,6 +38,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // Output tile: 4 waves x MT 16-pixel row segments each, arranged as MX segments side by side
 // and MT/MX rows per wave: (16/MX) rows x (16*MX) columns.  Wider tiles read longer contiguous
 // runs of a channels-last row (fewer, larger DRAM bursts) for a slightly larger halo.
+#ifndef MIS_CSE_14
+#define MIS_CSE_14 1
+#endif
 #ifndef MIS_PRE_REL
 #define MIS_PRE_REL 0
 #endif
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
         }                                                                                                \
       }                                                                                                  \
       Frag xa[2][MT], wf[2][NT];                                                                         \
-      if constexpr (NT < 4) {                                                                            \
+      if constexpr (NT < 4 && !(MIS_CSE_14 && NT == 1 && CPG == 4)) {                                       \
         /* fragments of step s+1 are fetched from LDS while the MFMAs of step s run (two register */     \
         /* sets); the scheduling barrier keeps the compiler from hoisting every step's reads up */       \
         LOAD_FRAGS(0, 0)                                                                                 \
