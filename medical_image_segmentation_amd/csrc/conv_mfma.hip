@@ -41,6 +41,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #ifndef MIS_CSE_14
 #define MIS_CSE_14 1
 #endif
+#ifndef MIS_DEEP
+#define MIS_DEEP 1
+#endif
 #ifndef MIS_PRE_REL
 #define MIS_PRE_REL 0
 #endif
@@ -294,7 +297,13 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
 #pragma unroll
   for (int n = 0; n < NT; n++) s1[n] = s2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 hreg[HALO_IT], wreg[W_IT];
+  // DEEP (weights resident, one K chunk per tile): two register sets, the halo of tile t+2 is
+  // requested while tile t computes, so a load has two tile times to arrive.  Measured on the
+  // write-heavy layers: reads queued behind a saturated store path otherwise stall the pipeline
+  // (time = read phase + write phase instead of their maximum).
+  constexpr bool DEEP = (CPG < 4) && (MIS_DEEP != 0) && !BNS;      // (the fused-sums epilogue twice over would spill)
+  u32x4 hreg[HALO_IT], hregB[DEEP ? HALO_IT : 1], wreg[W_IT];
+#define HREG hreg
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, n_chunks * NS * nt_total * 1024, 0x00020000);
 
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
       const bool ok = (unsigned)(x0_ + (PRE ? h_px[PRE ? i : 0] : halo_px(i))) < (unsigned)W;            \
       const unsigned rel_ = PRE_REL ? h_rel[PRE_REL ? i : 0] : halo_rel(i);                              \
-      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(ok ? base_ + rel_ : OOB), 0, 0);        \
+      HREG[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(ok ? base_ + rel_ : OOB), 0, 0);        \
     }                                                                                                    \
   }
   // STORE_HALO(P, CHUNK): registers -> LDS.  For a lazily stored input the BatchNorm affine and
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
 #define STORE_HALO(P, CHUNK)                                                                             \
   {                                                                                                      \
     _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
-      u32x4 val = hreg[i];                                                                               \
+      u32x4 val = HREG[i];                                                                               \
       if (((CHUNK) >= n_chunks_a) ? (affb != nullptr) : (affa != nullptr)) {                             \
         const int v = tid + i * CM_THREADS;                                                              \
         const int pos = v / CPG, cg = v % CPG;                                                           \
@@ -497,30 +506,8 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     _Pragma("unroll") for (int n = 0; n < NT; n++)                                                       \
       wf[BUF][n] = *reinterpret_cast<const Frag*>(&wl[((S) * NT + n) * 64 + lane]);                      \
   }
-  // One stage = one (tile, 32-channel chunk): halo (+ weights) registers -> LDS, issue the next
-  // stage's global loads, then the MFMAs.  The loads are issued unconditionally (dead stages
-  // read out of range = zeros).  FIRST_CHUNK: the accumulators start from the bias.
-#define STAGE(CHUNK, FIRST_CHUNK)                                                                        \
-  {                                                                                                      \
-    if (live) {                                                                                          \
-      __syncthreads(); /* every wave is done reading the previous stage */                               \
-      if constexpr (!PRE) asm volatile("" : "+v"(tid_l));                                                \
-      STORE_HALO(cur, (CHUNK))                                                                           \
-      if constexpr (!W_ONCE) {                                                                           \
-        if (!w_resident || first) STORE_W()                                                              \
-        first = false;                                                                                   \
-      }                                                                                                  \
-      __syncthreads();                                                                                   \
-    }                                                                                                    \
-    if constexpr (!PRE) asm volatile("" : "+v"(tid_l));                                                  \
-    if ((CHUNK) + 1 < nch) {                                                                             \
-      LOAD_HALO(cur, (CHUNK) + 1, true)                                                                  \
-      if constexpr (!W_ONCE) LOAD_W((CHUNK) + 1, true)                                                   \
-    } else {                                                                                             \
-      LOAD_HALO(nxt, 0, it + 1 < t_count)                                                                \
-      if constexpr (!W_ONCE) LOAD_W(0, (!w_resident || !live) && it + 1 < t_count)                       \
-    }                                                                                                    \
-    __builtin_amdgcn_sched_barrier(0); /* loads stay ahead of the MFMAs (the scheduler would sink them) */ \
+  // the MFMAs of one stage (accumulators start from the bias on a tile's first chunk)
+#define STAGE_MFMA(FIRST_CHUNK)                                                                          \
     if (live) {                                                                                          \
       if (FIRST_CHUNK) {                                                                                 \
         _Pragma("unroll") for (int n = 0; n < NT; n++) {                                                 \
@@ -548,7 +535,33 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
             _Pragma("unroll") for (int m = 0; m < MT; m++) mfma_step(wf[0][n], xa[0][m], acc[m][n]);     \
         }                                                                                                \
       }                                                                                                  \
+    }
+
+  // One stage = one (tile, 32-channel chunk): halo (+ weights) registers -> LDS, issue the next
+  // stage's global loads, then the MFMAs.  The loads are issued unconditionally (dead stages
+  // read out of range = zeros).  FIRST_CHUNK: the accumulators start from the bias.
+#define STAGE(CHUNK, FIRST_CHUNK)                                                                        \
+  {                                                                                                      \
+    if (live) {                                                                                          \
+      __syncthreads(); /* every wave is done reading the previous stage */                               \
+      if constexpr (!PRE) asm volatile("" : "+v"(tid_l));                                                \
+      STORE_HALO(cur, (CHUNK))                                                                           \
+      if constexpr (!W_ONCE) {                                                                           \
+        if (!w_resident || first) STORE_W()                                                              \
+        first = false;                                                                                   \
+      }                                                                                                  \
+      __syncthreads();                                                                                   \
     }                                                                                                    \
+    if constexpr (!PRE) asm volatile("" : "+v"(tid_l));                                                  \
+    if ((CHUNK) + 1 < nch) {                                                                             \
+      LOAD_HALO(cur, (CHUNK) + 1, true)                                                                  \
+      if constexpr (!W_ONCE) LOAD_W((CHUNK) + 1, true)                                                   \
+    } else {                                                                                             \
+      LOAD_HALO(nxt, 0, it + 1 < t_count)                                                                \
+      if constexpr (!W_ONCE) LOAD_W(0, (!w_resident || !live) && it + 1 < t_count)                       \
+    }                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0); /* loads stay ahead of the MFMAs (the scheduler would sink them) */ \
+    STAGE_MFMA(FIRST_CHUNK)                                                                              \
   }
 
   // The loop runs one extra, leading iteration (it = -1) that only issues the first tile's
@@ -563,17 +576,50 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   for (int m = 0; m < MT; m++)
 #pragma unroll
     for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int it = -1; it < t_count; it++) {
-    const bool live = it >= 0;
-    const int nch = live ? n_chunks : 1;
-    if (live) nxt.next(tiles_x, tiles_y);
-    // the first chunk is peeled: its wait sits behind an epilogue's stores, the others' do not
-    STAGE(0, true)
-    for (int chunk = 1; chunk < nch; chunk++) STAGE(chunk, false)
-    EPILOGUE()
-    cur = nxt;
+  if constexpr (DEEP) {
+    // Two tiles per trip, one per register set; two leading load-only halves (it = -2, -1) give
+    // every path into a wait the same shape, as above.  `cur` = the tile computed, `nxt` = the
+    // tile requested (two ahead).
+#define HALF(IDX)                                                                                        \
+  {                                                                                                      \
+    const int idx_ = (IDX);                                                                              \
+    const bool live = idx_ >= 0 && idx_ < t_count;                                                       \
+    if (live) {                                                                                          \
+      __syncthreads();                                                                                   \
+      STORE_HALO(cur, 0)                                                                                 \
+      __syncthreads();                                                                                   \
+    }                                                                                                    \
+    LOAD_HALO(nxt, 0, idx_ + 2 < t_count)                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    STAGE_MFMA(true)                                                                                     \
+    EPILOGUE()                                                                                           \
+    if (live) cur.next(tiles_x, tiles_y);                                                                \
+    nxt.next(tiles_x, tiles_y);                                                                          \
+  }
+    for (int it = -2; it < t_count; it += 2) {
+      HALF(it)
+#undef HREG
+#define HREG hregB
+      HALF(it + 1)
+#undef HREG
+#define HREG hreg
+    }
+#undef HALF
+  } else {
+    for (int it = -1; it < t_count; it++) {
+      const bool live = it >= 0;
+      const int nch = live ? n_chunks : 1;
+      if (live) nxt.next(tiles_x, tiles_y);
+      // the first chunk is peeled: its wait sits behind an epilogue's stores, the others' do not
+      STAGE(0, true)
+      for (int chunk = 1; chunk < nch; chunk++) STAGE(chunk, false)
+      EPILOGUE()
+      cur = nxt;
+    }
   }
 #undef STAGE
+#undef STAGE_MFMA
+#undef HREG
 #undef LOAD_FRAGS
 
   if (partials) {
