@@ -81,7 +81,11 @@ class UNet(nn.Module):
     def _pack_weights(self, dtype):
         """All 3x3 conv weights -> the kernels' operand images in one launch (only when a weight
         changed since the last call)."""
-        weights = [blk[0].weight for m in self.modules() if isinstance(m, DoubleConv) for blk in (m.cbr1, m.cbr2)]
+        convs = self.__dict__.get("_mis_convs")
+        if convs is None:         # the nn.Conv2d modules (their .weight may be re-assigned, the modules stay)
+            convs = [blk[0] for m in self.modules() if isinstance(m, DoubleConv) for blk in (m.cbr1, m.cbr2)]
+            self.__dict__["_mis_convs"] = convs
+        weights = [c.weight for c in convs]
         packer = self.__dict__.get("_mis_packer")
         if packer is None or not packer.valid_for(weights, dtype):
             packer = F_.WeightPacker(weights, dtype)

@@ -78,10 +78,92 @@ def _fusable(optimizer, params):
     return clip == listed and len(listed) > 0
 
 
+class _Fast:
+    """What `clip_and_step` established about an (optimizer, params) pair on its first fused call,
+    so that later calls only re-check what can change between steps."""
+
+    def __init__(self):
+        self.param_ids = None
+        self.groups = None        # [(group dict, [params])]
+        self.states = None        # [state dict per param], same order as the pointer rows
+        self.static = None        # [(p ptr, exp_avg ptr, exp_avg_sq ptr, numel)]
+        self.step_tensors = None
+        self.step = None          # the value every step tensor holds
+
+
+_FAST = {}
+
+
+def _group_ok(g):
+    return not (g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable")
+                or isinstance(g["lr"], torch.Tensor))
+
+
+def _fast_path(optimizer, params):
+    """The cached description if nothing structural changed since it was built, else None."""
+    f = _FAST.get(id(optimizer))
+    if f is None or f.param_ids != [id(p) for p in params]:
+        return None
+    state = optimizer.state
+    for (g, ps) in f.groups:
+        if not _group_ok(g):
+            return None
+    for p, s, (sp, sm, sv, _) in zip((p for _, ps in f.groups for p in ps), f.states, f.static):
+        gr = p.grad
+        if (gr is None or gr.dtype != torch.float32 or not gr.is_contiguous() or state.get(p) is not s
+                or p.data_ptr() != sp or s["exp_avg"].data_ptr() != sm or s["exp_avg_sq"].data_ptr() != sv):
+            return None
+    if float(f.step_tensors[0]) != f.step:
+        return None
+    return f
+
+
 def clip_and_step(optimizer, params, max_norm=1.0):
     """clip_grad_norm_(params, max_norm) + optimizer.step().  Returns the total gradient norm (a
     0-dim tensor), like clip_grad_norm_."""
     params = [p for p in params]
+    fast = _fast_path(optimizer, params)
+    if fast is not None:
+        return _launch(optimizer, fast, max_norm)
+    _FAST.pop(id(optimizer), None)
+    return _clip_and_step_checked(optimizer, params, max_norm)
+
+
+def _launch(optimizer, f, max_norm):
+    dev = f.groups[0][1][0].device
+    rows = [(sp, p.grad.data_ptr(), sm, sv, n)
+            for p, (sp, sm, sv, n) in zip((p for _, ps in f.groups for p in ps), f.static)]
+    plan = _PLANS[id(optimizer)]
+    if plan.rows != rows:
+        plan.upload(rows)
+    st = F_._stream()
+    ws = F_.workspace(plan.ws_bytes, dev)
+    norm = torch.empty((), dtype=torch.float32, device=dev)
+    n_t = len(rows)
+    call("mis_grad_sqsum", plan.descs.data_ptr(), plan.prefix.data_ptr(), n_t, plan.n_chunks, ws.data_ptr(), st)
+    step = int(f.step) + 1
+    for (g, ps), (c0, c1) in zip(f.groups, plan.group_chunks):
+        b1, b2 = g["betas"]
+        call("mis_clip_adamw_step", plan.descs.data_ptr(), plan.prefix.data_ptr(), n_t, c0, c1, plan.n_chunks,
+             ws.data_ptr(), float(max_norm), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+             float(g["weight_decay"]), step, 1, norm.data_ptr() if c0 == 0 else None, st)
+    torch._foreach_add_(f.step_tensors, 1)
+    f.step = float(step)
+    # the kernels wrote through raw pointers: tell autograd (and anything keyed on tensor versions,
+    # e.g. cached operand images of the weights) that these tensors changed
+    touched = []
+    for _, ps in f.groups:
+        touched += ps
+        touched += [p.grad for p in ps]
+    for s in f.states:
+        touched += [s["exp_avg"], s["exp_avg_sq"]]
+    torch._C._increment_version(touched)
+    return norm
+
+
+def _clip_and_step_checked(optimizer, params, max_norm):
+    """Full validation of the (optimizer, params) pair; on success the first fused step and the
+    cached description for the following ones."""
     if not _fusable(optimizer, params):
         norm = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
         optimizer.step()
@@ -127,25 +209,17 @@ def clip_and_step(optimizer, params, max_norm=1.0):
             group_chunks.append((c0, c))
         prefix.append(c)
         plan = _PLANS[id(optimizer)] = _Plan(sizes, group_chunks, prefix, dev)
-    if plan.rows != rows:
-        plan.upload(rows)
-    st = torch.cuda.current_stream().cuda_stream
-    ws = F_.workspace(query("mis_clip_adamw_workspace_bytes", plan.n_chunks), dev)
-    norm = torch.empty((), dtype=torch.float32, device=dev)
-    n_t = len(rows)
-    call("mis_grad_sqsum", plan.descs.data_ptr(), plan.prefix.data_ptr(), n_t, plan.n_chunks, ws.data_ptr(), st)
-    for (g, ps), (c0, c1), step in zip(groups, plan.group_chunks, steps):
-        b1, b2 = g["betas"]
-        call("mis_clip_adamw_step", plan.descs.data_ptr(), plan.prefix.data_ptr(), n_t, c0, c1, plan.n_chunks,
-             ws.data_ptr(), float(max_norm), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-             float(g["weight_decay"]), step, 1, norm.data_ptr() if c0 == 0 else None, st)
-        for p in ps:
-            optimizer.state[p]["step"] += 1
-        # the kernels wrote through raw pointers: tell autograd (and anything keyed on tensor
-        # versions, e.g. cached operand images of the weights) that these tensors changed
-        touched = list(ps) + [p.grad for p in ps]
-        for p in ps:
-            s = optimizer.state[p]
-            touched += [s["exp_avg"], s["exp_avg_sq"]]
-        torch._C._increment_version(touched)
-    return norm
+    plan.ws_bytes = query("mis_clip_adamw_workspace_bytes", plan.n_chunks)
+    if len(set(steps)) != 1:              # groups at different step counts: torch handles that
+        norm = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+        optimizer.step()
+        return norm
+    f = _Fast()
+    f.param_ids = [id(p) for p in params]
+    f.groups = groups
+    f.states = [optimizer.state[p] for _, ps in groups for p in ps]
+    f.static = [(r[0], r[2], r[3], r[4]) for r in rows]
+    f.step_tensors = [s_["step"] for s_ in f.states]
+    f.step = float(steps[0] - 1)
+    _FAST[id(optimizer)] = f
+    return _launch(optimizer, f, max_norm)
