@@ -217,6 +217,20 @@ def test_fused_clip_adamw_matches_torch():
             assert rel_err(sa["exp_avg"], sb["exp_avg"]) < 2e-6 and rel_err(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 2e-6
     oc = torch.optim.AdamW(groups(mk()), betas=(0.95, 0.999), eps=1e-8)
     oc.load_state_dict(oa.state_dict())          # same state layout as torch's own
+    assert all(set(v.keys()) == {"step", "exp_avg", "exp_avg_sq"} for v in oa.state_dict()["state"].values())
+    # reloading the state replaces the moment tensors: the cached description must notice
+    oa.load_state_dict(oa.state_dict())
+    ob.load_state_dict(ob.state_dict())
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        g = T(dg.hash_normalish(shapes[i], 1400 + i, std=0.5)).to(DEV)
+        a.grad, b.grad = g.clone(), g.clone()
+    clip_and_step(oa, pa, max_norm=1.0)
+    torch.nn.utils.clip_grad_norm_(pb, max_norm=1.0)
+    ob.step()
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 4e-6 * float(b.abs().max()) + 1e-8
+        assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 4
+        assert rel_err(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 4e-6
     # an optimizer the fused path does not take runs torch's calls unchanged
     ps = mk()
     sgd = torch.optim.SGD(ps, lr=0.1)
