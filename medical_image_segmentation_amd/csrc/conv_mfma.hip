@@ -660,6 +660,34 @@ struct FwdPlan {
   size_t lds;
 };
 
+// Workgroups of one variant that fit a CU together (registers and LDS), asked from the runtime
+// once per variant and LDS size; 3 when there is no device to ask.
+template <typename T, int NT>
+int fwd_resident_k(int CPG, size_t lds) {
+  const void* k = nullptr;
+  switch (CPG) {
+    case 1: k = (const void*)conv3x3_mfma_kernel<T, NT, 1, false>; break;
+    case 2: k = (const void*)conv3x3_mfma_kernel<T, NT, 2, false>; break;
+    case 3: k = (const void*)conv3x3_mfma_kernel<T, NT, 3, false>; break;
+    default: k = (const void*)conv3x3_mfma_kernel<T, NT, 4, false>; break;
+  }
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, CM_THREADS, lds) != hipSuccess || n < 1) {
+    (void)hipGetLastError();
+    return 3;
+  }
+  return n;
+}
+
+template <typename T>
+int fwd_resident(int NT, int CPG, size_t lds) {
+  static int cache[5][5][8] = {};                 // [NT][CPG][lds / 32 KiB]
+  int& c = cache[NT][CPG][(lds >> 15) & 7];
+  if (c == 0) c = NT == 4 ? fwd_resident_k<T, 4>(CPG, lds) : NT == 2 ? fwd_resident_k<T, 2>(CPG, lds)
+                                                                     : fwd_resident_k<T, 1>(CPG, lds);
+  return c;
+}
+
 // Ca_in: channels of the first input tensor (== Cin for one tensor); Cout_a: channels of the
 // first output tensor (== Cout for one tensor).
 template <typename T>
@@ -703,18 +731,23 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
   p.tiles_x = (W + TW - 1) / TW;
   p.tiles_y = (H + TH - 1) / TH;
   p.n_tiles = B * p.tiles_x * p.tiles_y;
-  static int target = -1;                     // total workgroups per launch (MIS_CONV_GRID overrides, tuning)
-  if (target < 0) {
+  p.lds = (size_t)(TH + 2) * HW_ * (p.CPG == 4 ? 96 : (p.CPG | 1) * 16) + 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
+          (size_t)p.NT * 16 * 4 + 2 * (size_t)Cin * 4 + 4 * (size_t)p.NT * 16 * 4;
+  // Total workgroups per launch: as many as are resident at once on 256 CUs, so the persistent
+  // workgroups run as one round (a second, partly filled round costs a whole tile range: 10-25 %
+  // on the 128^2 and 256^2 layers).  MIS_CONV_GRID overrides (tuning).
+  static int forced = -1;
+  if (forced < 0) {
     const char* e = getenv("MIS_CONV_GRID");
-    target = e ? atoi(e) : 768;
-    if (target < 64) target = 768;
+    forced = e ? atoi(e) : 0;
   }
+  // (The 8-channel-input variants stream many tiles per workgroup and measured best at 768 whatever
+  // their residency: shorter ranges balance better than one round of long ones.)
+  const int target = forced >= 64 ? forced : p.CPG == 1 ? 768 : 256 * fwd_resident<T>(p.NT, p.CPG, p.lds);
   int gx = target / p.grid_y;
   if (gx < 256) gx = 256;
   if (gx > p.n_tiles) gx = p.n_tiles;
   p.grid_x = gx;
-  p.lds = (size_t)(TH + 2) * HW_ * (p.CPG == 4 ? 96 : (p.CPG | 1) * 16) + 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
-          (size_t)p.NT * 16 * 4 + 2 * (size_t)Cin * 4 + 4 * (size_t)p.NT * 16 * 4;
   return true;
 }
 
@@ -1225,7 +1258,15 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1) 
   const int nout = p.n_co_blocks * p.n_ci_blocks;
   const double act_bytes = (double)B * H * W * (Cin + Cout) * sizeof(T);
   const double dw_bytes = 36.0 * Cin * Cout;
-  int ns = 768 / nout;
+  // one round of resident workgroups on 256 CUs: the four-wave variants fit three per CU, the
+  // 32x32 K-split variant two, the 64x64 block (eight waves) one.  MIS_WGRAD_GRID overrides (tuning).
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("MIS_WGRAD_GRID");
+    forced = e ? atoi(e) : 0;
+  }
+  const int target = forced >= 64 ? forced : p.cfg == 4 ? 256 : p.cfg == 3 ? 512 : 768;
+  int ns = target / nout;
   const int ns_slab = (int)(act_bytes / dw_bytes);
   if (ns > ns_slab) ns = ns_slab;
   const int ns_fill = (256 + nout - 1) / nout;          // at least one workgroup per CU

@@ -68,9 +68,9 @@ _WS = {}
 
 
 def workspace(nbytes, device):
-    """One growing scratch buffer per device.  Every kernel that uses it runs on the
-    current stream, so consecutive users are ordered by the stream itself."""
-    key = (device.type, device.index)
+    """One growing scratch buffer per (device, stream).  Every kernel that uses it runs on that
+    stream, so consecutive users are ordered by the stream itself."""
+    key = (device.type, device.index, _stream() if device.type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
