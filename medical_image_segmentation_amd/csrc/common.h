@@ -45,11 +45,29 @@ __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
-// 64-lane butterfly sum: every lane ends with the total.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+// Cross-lane sums on the DPP path (no LDS round trips: a `__shfl_xor` is a ds_bpermute plus a wait
+// for it, ~100 cycles each, which dominates epilogues that reduce dozens of values).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over each row of 16 lanes; every lane of the row ends with the row's total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);     // row_half_mirror: quad q with quad 1-q of its 8 lanes
+  v += dpp_move<0x140>(v);     // row_mirror: the two halves of the row
   return v;
+}
+// 64-lane sum: every lane ends with the total (the four row totals are read as scalars).
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // Block sum of NV values per thread through LDS; result valid in thread 0..NV-1 style:

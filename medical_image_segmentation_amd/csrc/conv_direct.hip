@@ -142,21 +142,25 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// image-facing first layer (CIN = 1 or 3 input channels): one thread = one pixel x CO_T output
-// channels, all 9*CIN taps loaded up front (clamped address, zero selected for the padding) so
-// the loads are in flight together; weights broadcast from LDS; 16-byte coalesced stores.
+// image-facing first layer (CIN = 1 or 3 input channels).  A workgroup stages the (16+2)x(64+2)
+// halo of a 16x64-pixel tile in LDS as float32 (lazy-input affine applied, padding = 0), so the
+// compute loop has no bounds checks and no global address arithmetic: a lane owns one column and
+// 4 consecutive rows, reads its 6x3 window once (4.5 LDS reads per pixel instead of 9 global
+// loads), and stores 16 bytes per pixel with consecutive lanes on consecutive pixels.
 // HBM-bound on the output write.
 // ---------------------------------------------------------------------------------
+constexpr int F_TW = 64, F_TH = 16;
+
 template <typename T, int CIN>
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
     const T* __restrict__ x, const T* __restrict__ wp /*[9][Cout][CIN]*/, const float* __restrict__ bias,
     T* __restrict__ z, float* __restrict__ partials /*[gridDim.x][2][Cout] or null*/, int B, int H, int W, int Cout,
-    const float* __restrict__ in_aff) {
+    const float* __restrict__ in_aff, int tiles_x, int tiles_y, int n_tiles) {
   __shared__ __attribute__((aligned(16))) float wl[9 * CIN][CO_T];
   __shared__ float red[2 * CO_T * (CD_THREADS / 64)];
-  const int tid = threadIdx.x;
+  __shared__ float halo[CIN][F_TH + 2][F_TW + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int co0 = blockIdx.y * CO_T;
-  const unsigned n_pix = (unsigned)B * H * W;
   for (int i = tid; i < 9 * CIN * CO_T; i += CD_THREADS) {
     const int j = i % CO_T, k = i / CO_T, ci = k % CIN, tap = k / CIN;
     wl[k][j] = (co0 + j < Cout) ? to_f32(wp[((int64_t)tap * Cout + co0 + j) * CIN + ci]) : 0.f;
@@ -173,58 +177,103 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
     asc[c] = in_aff ? in_aff[c] : 1.f;
     ash[c] = in_aff ? in_aff[CIN + c] : 0.f;
   }
-  __syncthreads();
   const bool vec_store = (Cout % CO_T == 0) && (((uintptr_t)z & 15) == 0);
-  for (unsigned pix = blockIdx.x * CD_THREADS + tid; pix < n_pix; pix += gridDim.x * CD_THREADS) {
-    const unsigned row = pix / (unsigned)W;
-    const int px = (int)(pix - row * (unsigned)W), py = (int)(row % (unsigned)H);
-    float xv[9][CIN];
+  // The halo of the workgroup's next tile is requested (raw, clamped address, validity kept as a
+  // bit mask) before the current tile is computed, so its latency hides under the FMAs and stores.
+  constexpr int F_HALO = (F_TH + 2) * (F_TW + 2), F_IT = (F_HALO + CD_THREADS - 1) / CD_THREADS;
+  T raw[F_IT][CIN];
+  unsigned okm = 0;
+  auto request = [&](int t) {
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    okm = 0;
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++) {
-      const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const T* xp = x + (ok ? (int64_t)pix + (tap / 3 - 1) * W + (tap % 3 - 1) : (int64_t)pix) * CIN;
+    for (int i = 0; i < F_IT; i++) {
+      const int e = tid + i * CD_THREADS;
+      const int hy = e / (F_TW + 2), hx = e % (F_TW + 2);
+      const int gy = ty * F_TH - 1 + hy, gx = tx * F_TW - 1 + hx;
+      const bool ok = e < F_HALO && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      okm |= ok ? (1u << i) : 0u;
+      const T* xp = x + (ok ? ((int64_t)(b * H + gy) * W + gx) * CIN : 0);
 #pragma unroll
-      for (int c = 0; c < CIN; c++) {
-        float v = to_f32(xp[c]);
-        if (in_aff) v = to_f32(from_f32<T>(fmaxf(v * asc[c] + ash[c], 0.f)));
-        xv[tap][c] = ok ? v : 0.f;
+      for (int c = 0; c < CIN; c++) raw[i][c] = xp[c];
+    }
+  };
+  if ((int)blockIdx.x < n_tiles) request(blockIdx.x);
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int x0 = tx * F_TW, y0 = ty * F_TH;
+    __syncthreads();                                   // previous tile's readers (and the weight staging)
+#pragma unroll
+    for (int i = 0; i < F_IT; i++) {
+      const int e = tid + i * CD_THREADS;
+      if (e < F_HALO) {
+        const int hy = e / (F_TW + 2), hx = e % (F_TW + 2);
+#pragma unroll
+        for (int c = 0; c < CIN; c++) {
+          float v = to_f32(raw[i][c]);
+          if (in_aff) v = to_f32(from_f32<T>(fmaxf(v * asc[c] + ash[c], 0.f)));
+          halo[c][hy][hx] = ((okm >> i) & 1u) ? v : 0.f;
+        }
       }
     }
-    float acc[CO_T];
+    __syncthreads();
+    if (t + (int)gridDim.x < n_tiles) request(t + gridDim.x);
+    float xv[CIN][6][3];
 #pragma unroll
-    for (int j = 0; j < CO_T; j++) acc[j] = bv[j];
+    for (int c = 0; c < CIN; c++)
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) xv[c][rr][kx] = halo[c][4 * wv + rr][lane + kx];
+    float acc[4][CO_T];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int j = 0; j < CO_T; j++) acc[r][j] = bv[j];
 #pragma unroll
     for (int k = 0; k < 9 * CIN; k++) {
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[k][0]), w1 = *reinterpret_cast<const f32x4*>(&wl[k][4]);
-      const float v = xv[k / CIN][k % CIN];
+      const int tap = k / CIN, c = k % CIN;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        acc[j] += v * w0[j];
-        acc[4 + j] += v * w1[j];
+      for (int r = 0; r < 4; r++) {
+        const float v = xv[c][r + tap / 3][tap % 3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          acc[r][j] += v * w0[j];
+          acc[r][4 + j] += v * w1[j];
+        }
       }
     }
+    const int gx = x0 + lane;
 #pragma unroll
-    for (int j = 0; j < CO_T; j++) {
-      st[j] += acc[j];
-      st[CO_T + j] += acc[j] * acc[j];
-    }
-    T* zp = z + (int64_t)pix * Cout + co0;
-    if (vec_store) {
-      if constexpr (sizeof(T) == 2) {
-        vstore<T, CO_T>(zp, acc);
-      } else {
-        float lo[4] = {acc[0], acc[1], acc[2], acc[3]}, hi[4] = {acc[4], acc[5], acc[6], acc[7]};
-        vstore<T, 4>(zp, lo);
-        vstore<T, 4>(zp + 4, hi);
+    for (int r = 0; r < 4; r++) {
+      const int gy = y0 + 4 * wv + r;
+      if (gy < H && gx < W) {
+#pragma unroll
+        for (int j = 0; j < CO_T; j++) {
+          st[j] += acc[r][j];
+          st[CO_T + j] += acc[r][j] * acc[r][j];
+        }
+        T* zp = z + ((int64_t)(b * H + gy) * W + gx) * Cout + co0;
+        if (vec_store) {
+          if constexpr (sizeof(T) == 2) {
+            vstore<T, CO_T>(zp, acc[r]);
+          } else {
+            float lo[4] = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            float hi[4] = {acc[r][4], acc[r][5], acc[r][6], acc[r][7]};
+            vstore<T, 4>(zp, lo);
+            vstore<T, 4>(zp + 4, hi);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CO_T; j++)
+            if (co0 + j < Cout) zp[j] = from_f32<T>(acc[r][j]);
+        }
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < CO_T; j++)
-        if (co0 + j < Cout) zp[j] = from_f32<T>(acc[j]);
     }
   }
   if (partials) {
+    __syncthreads();
     block_sum<2 * CO_T>(st, red);
     if (tid < 2 * CO_T) {
       float v = 0.f;
@@ -237,24 +286,24 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// direct 3x3 weight gradient: grid (pixel blocks, Cout/CO_T, Cin); a thread walks pixels and
-// keeps 9 x CO_T accumulators for one input channel; each workgroup writes its 72 sums to a
-// row of partials [blk][Cout][Cin][9] that a second launch adds in a fixed order (no atomics:
-// bitwise reproducible).
+// direct 3x3 weight gradient: grid (tile walkers, Cout/CO_T, Cin).  Same tiling as the first-layer
+// forward: the halo of input channel `ci` is staged in LDS (affine applied, padding = 0), a lane
+// owns one column and 4 rows of the 16x64 tile, reads its 6x3 window and its 4 gradient vectors
+// (16 bytes each, coalesced) and keeps 9 x CO_T accumulators; each workgroup writes its 72 sums
+// to a row of partials [blk][Cout][Cin][9] that a second launch adds in a fixed order (no
+// atomics: bitwise reproducible).
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const T* __restrict__ x,
                                                                           const T* __restrict__ dz,
                                                                           float* __restrict__ partials, int B, int H,
-                                                                          int W, int Cin, int Cout, int pix_per_blk,
+                                                                          int W, int Cin, int Cout, int tiles_x,
+                                                                          int tiles_y, int n_tiles,
                                                                           const float* __restrict__ x_aff) {
   __shared__ float red[9 * CO_T * (CD_THREADS / 64)];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ float halo[F_TH + 2][F_TW + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int co0 = blockIdx.y * CO_T, ci = blockIdx.z;
-  const unsigned n_pix = (unsigned)B * H * W;
-  const unsigned p0 = blockIdx.x * (unsigned)pix_per_blk;
-  unsigned p1 = p0 + (unsigned)pix_per_blk;
-  if (p1 > n_pix) p1 = n_pix;
   float acc[9][CO_T];
 #pragma unroll
   for (int t = 0; t < 9; t++)
@@ -266,38 +315,76 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
     asc = x_aff[ci];
     ash = x_aff[Cin + ci];
   }
-  for (unsigned pix = p0 + tid; pix < p1; pix += CD_THREADS) {
-    const unsigned row = pix / (unsigned)W;
-    const int px = (int)(pix - row * (unsigned)W), py = (int)(row % (unsigned)H);
-    float g[CO_T];
-    if (vec_dz) {
-      vload<T, CO_T>(dz + (int64_t)pix * Cout + co0, g);
-    } else {
+  // next tile's halo values and gradient vectors are requested (raw, clamped addresses, validity
+  // as bit masks) before the current tile's FMAs: one tile of look-ahead hides the memory latency
+  constexpr int F_HALO = (F_TH + 2) * (F_TW + 2), F_IT = (F_HALO + CD_THREADS - 1) / CD_THREADS;
+  T raw[F_IT];
+  T graw[4][CO_T];
+  unsigned okm = 0, gokm = 0;
+  auto request = [&](int t) {
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    okm = gokm = 0;
 #pragma unroll
-      for (int j = 0; j < CO_T; j++) g[j] = (co0 + j < Cout) ? to_f32(dz[(int64_t)pix * Cout + co0 + j]) : 0.f;
+    for (int i = 0; i < F_IT; i++) {
+      const int e = tid + i * CD_THREADS;
+      const int hy = e / (F_TW + 2), hx = e % (F_TW + 2);
+      const int gy = ty * F_TH - 1 + hy, gx = tx * F_TW - 1 + hx;
+      const bool ok = e < F_HALO && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      okm |= ok ? (1u << i) : 0u;
+      raw[i] = x[ok ? ((int64_t)(b * H + gy) * W + gx) * Cin + ci : 0];
     }
-    // all 9 taps are loaded first (clamped address, zero selected for the padding): the loads are
-    // in flight together instead of one latency per tap
-    float xv[9];
+    const int gx = tx * F_TW + lane;
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      float v = to_f32(x[(ok ? (int64_t)pix + (t / 3 - 1) * W + (t % 3 - 1) : (int64_t)pix) * Cin + ci]);
-      if (x_aff) v = to_f32(from_f32<T>(fmaxf(v * asc + ash, 0.f)));
-      xv[t] = ok ? v : 0.f;
+    for (int r = 0; r < 4; r++) {
+      const int gy = ty * F_TH + 4 * wv + r;
+      const bool ok = gy < H && gx < W;
+      gokm |= ok ? (1u << r) : 0u;
+      const T* gp = dz + (ok ? ((int64_t)(b * H + gy) * W + gx) * Cout + co0 : 0);
+      if (vec_dz) {
+        *reinterpret_cast<uint4*>(&graw[r][0]) = *reinterpret_cast<const uint4*>(gp);
+      } else {
+#pragma unroll
+        for (int j = 0; j < CO_T; j++) graw[r][j] = (ok && co0 + j < Cout) ? gp[j] : from_f32<T>(0.f);
+      }
     }
+  };
+  if ((int)blockIdx.x < n_tiles) request(blockIdx.x);
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int i = 0; i < F_IT; i++) {
+      const int e = tid + i * CD_THREADS;
+      if (e < F_HALO) {
+        float v = to_f32(raw[i]);
+        if (x_aff) v = to_f32(from_f32<T>(fmaxf(v * asc + ash, 0.f)));
+        halo[e / (F_TW + 2)][e % (F_TW + 2)] = ((okm >> i) & 1u) ? v : 0.f;
+      }
+    }
+    float g[4][CO_T];
 #pragma unroll
-      for (int j = 0; j < CO_T; j++) acc[t][j] += xv[t] * g[j];
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int j = 0; j < CO_T; j++) g[r][j] = ((gokm >> r) & 1u) ? to_f32(graw[r][j]) : 0.f;
+    __syncthreads();
+    if (t + (int)gridDim.x < n_tiles) request(t + gridDim.x);
+    float xv[6][3];
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) xv[rr][kx] = halo[4 * wv + rr][lane + kx];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+        for (int j = 0; j < CO_T; j++) acc[tp][j] += xv[r + tp / 3][tp % 3] * g[r][j];
   }
 #pragma unroll
   for (int t = 0; t < 9; t++)
 #pragma unroll
     for (int j = 0; j < CO_T; j++) {
       const float s = wave_sum(acc[t][j]);
-      if (lane == 0) red[wid * 72 + t * CO_T + j] = s;
+      if (lane == 0) red[wv * 72 + t * CO_T + j] = s;
     }
   __syncthreads();
   if (tid < 72) {
@@ -537,7 +624,7 @@ int conv1x1_bwd_t(const void* x, const float* x_aff, const void* dy, int64_t n_p
 // Entry points shared with the MFMA file (declared in conv_internal.h).
 #include "conv_internal.h"
 
-constexpr int CD_MAX_BLOCKS = 1024;
+constexpr int CD_MAX_BLOCKS = 2048;      // 8 workgroups per CU: the direct kernels hide latency with waves
 
 size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout) {
   return align256((size_t)CD_MAX_BLOCKS * 2 * Cout * sizeof(float));
@@ -556,9 +643,10 @@ int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const
   dim3 grid(gx, cdiv(Cout, CO_T));
   float* partials = stats ? (float*)workspace : nullptr;
   if (Cin == 1 || Cin == 3) {
+    const int ftx = cdiv(W, F_TW), fty = cdiv(H, F_TH);
 #define FIRST_LAUNCH(TT, CIN)                                                                               \
   conv3x3_first_kernel<TT, CIN><<<grid, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)wp, bias, (TT*)z, partials, B, \
-                                                             H, W, Cout, in_aff)
+                                                             H, W, Cout, in_aff, ftx, fty, B * ftx * fty)
     if (dtype == MIS_F32) {
       if (Cin == 1) FIRST_LAUNCH(float, 1); else FIRST_LAUNCH(float, 3);
     } else {
@@ -607,13 +695,12 @@ int conv3x3_direct_pack(const float* w, int Cw_out, int Cw_in, int transposed, i
 
 namespace {
 // pixel blocks of the direct weight gradient: enough workgroups to fill the chip across the
-// (Cout/CO_T, Cin) grid dimensions, at most 512 rows of partials
+// (Cout/CO_T, Cin) grid dimensions, at most 1024 rows of partials
 int wgrad_direct_blocks(int64_t n_pix, int Cin, int Cout) {
-  int nblk = (int)((n_pix + CD_THREADS * 16 - 1) / (CD_THREADS * 16));
+  int nblk = (int)((n_pix + F_TW * F_TH - 1) / (F_TW * F_TH));      // never more walkers than whole tiles
   const int per = cdiv(Cout, CO_T) * Cin;
   const int cap = per >= 1024 ? 1 : 1024 / per;
   if (nblk > cap) nblk = cap;
-  if (nblk > 512) nblk = 512;
   return nblk < 1 ? 1 : nblk;
 }
 }  // namespace
@@ -630,15 +717,15 @@ int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int 
     return MIS_ERR_ARG;
   }
   const int nblk = wgrad_direct_blocks(n_pix, Cin, Cout);
-  const int ppb = (int)((n_pix + nblk - 1) / nblk);
+  const int ftx = cdiv(W, F_TW), fty = cdiv(H, F_TH), n_tiles = B * ftx * fty;
   float* partials = (float*)workspace;
   dim3 grid(nblk, cdiv(Cout, CO_T), Cin);
   if (dtype == MIS_F32)
     conv3x3_wgrad_direct_kernel<float><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)dz, partials, B, H,
-                                                                     W, Cin, Cout, ppb, x_aff);
+                                                                     W, Cin, Cout, ftx, fty, n_tiles, x_aff);
   else
     conv3x3_wgrad_direct_kernel<bf16><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)dz, partials, B, H, W,
-                                                                    Cin, Cout, ppb, x_aff);
+                                                                    Cin, Cout, ftx, fty, n_tiles, x_aff);
   MIS_CHECK_LAUNCH("conv3x3_wgrad_direct_kernel");
   launch_reduce_partials(partials, nblk, 9 * Cin * Cout, dw, st);
   MIS_CHECK_LAUNCH("reduce_partials_kernel");

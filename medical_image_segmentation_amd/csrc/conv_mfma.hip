@@ -628,12 +628,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     for (int n = 0; n < NT; n++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        float a = s1[n][r], q = s2[n][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, WAVE);
-          q += __shfl_xor(q, o, WAVE);
-        }
+        const float a = row16_sum(s1[n][r]), q = row16_sum(s2[n][r]);
         if (col == 0) {
           red[wid][0][n * 16 + 4 * kg + r] = a;
           red[wid][1][n * 16 + 4 * kg + r] = q;
