@@ -432,6 +432,52 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_fwd_kernel(const T* __rest
   }
 }
 
+// The same conv with thread = (pixel, channel vector): consecutive lanes read the consecutive
+// 16-byte vectors of a pixel (a wave reads 1 KiB contiguous instead of 64 strided vectors), each
+// lane forms the partial dot products of its channels against register-resident weights, and the
+// CV = Cin/V lanes of a pixel are summed on the DPP path.  Lane 0 of the pixel stores.
+template <typename T, int V, int CO, int CV>
+__global__ __launch_bounds__(CD_THREADS) void conv1x1_fwd_cv_kernel(const T* __restrict__ x,
+                                                                    const float* __restrict__ w,
+                                                                    const float* __restrict__ bias,
+                                                                    T* __restrict__ y, int64_t n_pix,
+                                                                    const float* __restrict__ x_aff) {
+  constexpr int Cin = CV * V, PR = CD_THREADS / CV;
+  const int tid = threadIdx.x, cv = tid % CV, pr = tid / CV, c0 = cv * V;
+  float wr[CO][V], asc[V], ash[V], bv[CO];
+#pragma unroll
+  for (int j = 0; j < CO; j++) {
+    bv[j] = bias ? bias[j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < V; k++) wr[j][k] = w[j * Cin + c0 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    asc[k] = x_aff ? x_aff[c0 + k] : 1.f;
+    ash[k] = x_aff ? x_aff[Cin + c0 + k] : 0.f;
+  }
+  for (int64_t p = (int64_t)blockIdx.x * PR + pr; p < n_pix; p += (int64_t)gridDim.x * PR) {
+    float xv[V], acc[CO];
+    vload<T, V>(x + p * Cin + c0, xv);
+    if (x_aff) {
+#pragma unroll
+      for (int k = 0; k < V; k++) xv[k] = fmaxf(xv[k] * asc[k] + ash[k], 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < CO; j++) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < V; k++) a += xv[k] * wr[j][k];
+      if constexpr (CV >= 2) a += dpp_move<0xB1>(a);
+      if constexpr (CV >= 4) a += dpp_move<0x4E>(a);
+      if constexpr (CV >= 8) a += dpp_move<0x141>(a);
+      if constexpr (CV >= 16) a += dpp_move<0x140>(a);
+      acc[j] = a + bv[j];
+    }
+    if (cv == 0) vstore<T, CO>(y + p * CO, acc);
+  }
+}
+
 // Backward of the 1x1 conv.  Thread = (pixel, channel vector): consecutive lanes take the
 // consecutive channel vectors of a pixel, then the next pixel, so x / dx accesses of a wave are
 // contiguous.  Each thread writes its dx vector and accumulates dW[:, its channels] (and dbias
@@ -565,7 +611,14 @@ int conv1x1_fwd_t(const void* x, const float* x_aff, int64_t n_pix, int Cin, con
   constexpr int N = VecOf<T>::N;
   const size_t lds = ((size_t)Cin * CO + 2 * (size_t)Cin) * sizeof(float);
   const int grid = ew_grid(n_pix, CD_THREADS);
-  if (pick_vec<T>(Cin, x) == N)
+  const bool vec = pick_vec<T>(Cin, x) == N;
+  const int cvn = vec ? Cin / N : 0;
+  if (cvn == 2 || cvn == 4 || cvn == 8 || cvn == 16) {
+    const int g = ew_grid(n_pix * cvn, CD_THREADS);
+#define C1_CV(CVN) conv1x1_fwd_cv_kernel<T, N, CO, CVN><<<g, CD_THREADS, 0, st>>>((const T*)x, w, bias, (T*)y, n_pix, x_aff)
+    if (cvn == 2) C1_CV(2); else if (cvn == 4) C1_CV(4); else if (cvn == 8) C1_CV(8); else C1_CV(16);
+#undef C1_CV
+  } else if (vec)
     conv1x1_fwd_kernel<T, N, CO><<<grid, CD_THREADS, lds, st>>>((const T*)x, w, bias, (T*)y, n_pix, Cin, x_aff);
   else
     conv1x1_fwd_kernel<T, 1, CO><<<grid, CD_THREADS, lds, st>>>((const T*)x, w, bias, (T*)y, n_pix, Cin, x_aff);
