@@ -233,13 +233,25 @@ __global__ __launch_bounds__(EW_THREADS) void up_fwd_tiled_kernel(const T* __res
   }
   // stage the source pixels (rows ya.., cols xa.., clipped to the image)
   const T* src = low + (int64_t)b * h * w * C;
-  for (int i = tid; i < UP_SRC * UP_SRC * VC; i += EW_THREADS) {
-    const int cv = i % VC, pos = i / VC;
-    const int r = pos / UP_SRC, c = pos % UP_SRC;
-    const int gy = ya + r, gx = xa + c, ch = c0 + cv * G;
-    if (gy < h && gx < w && ch < C) {
+  // (all of a thread's loads are issued before the first use: one memory latency per tile)
+  constexpr int NV = UP_SRC * UP_SRC * VC, IT = (NV + EW_THREADS - 1) / EW_THREADS;
+  uint4 stg[IT];
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int e = tid + i * EW_THREADS;
+    const int cv = e % VC, pos = e / VC;
+    const int gy = ya + pos / UP_SRC, gx = xa + pos % UP_SRC, ch = c0 + cv * G;
+    const bool ok = e < NV && gy < h && gx < w && ch < C;
+    stg[i] = *reinterpret_cast<const uint4*>(src + (ok ? ((int64_t)gy * w + gx) * C + ch : 0));
+  }
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int e = tid + i * EW_THREADS;
+    const int cv = e % VC, pos = e / VC;
+    const int gy = ya + pos / UP_SRC, gx = xa + pos % UP_SRC, ch = c0 + cv * G;
+    if (e < NV && gy < h && gx < w && ch < C) {
       float v[G];
-      vload<T, G>(src + ((int64_t)gy * w + gx) * C + ch, v);
+      vload<T, G>(reinterpret_cast<const T*>(&stg[i]), v);
       affine_relu<G>(v, low_aff ? affl : nullptr, CC, cv * G);
       if (noise) {    // Dropout2d between the producer and the upsampling
 #pragma unroll
@@ -301,12 +313,23 @@ __global__ __launch_bounds__(EW_THREADS) void up_bwd_tiled_kernel(const T* __res
   const int Ho = 2 * h, Wo = 2 * w;
   const int yl0 = ty * UPB_T, xl0 = tx * UPB_T, YA = 2 * yl0 - 1, XA = 2 * xl0 - 1;
   const T* src = dout + (int64_t)b * Ho * Wo * Csrc;
-  for (int i = tid; i < UPB_SRC * UPB_SRC * VC; i += EW_THREADS) {
-    const int cv = i % VC, pos = i / VC;
+  // all of a thread's staging loads are issued before the first LDS store (clamped address, zero
+  // selected outside the image): one memory latency per tile instead of one per element
+  constexpr int NV = UPB_SRC * UPB_SRC * VC, IT = (NV + EW_THREADS - 1) / EW_THREADS;
+  uint4 stg[IT];
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int e = tid + i * EW_THREADS;
+    const int cv = e % VC, pos = e / VC;
     const int Y = YA + pos / UPB_SRC, X = XA + pos % UPB_SRC, ch = c0 + cv * G;
-    if (Y >= 0 && Y < Ho && X >= 0 && X < Wo && ch < C)
-      *reinterpret_cast<uint4*>(btile + pos * PITCH + cv * 16) =
-          *reinterpret_cast<const uint4*>(src + ((int64_t)Y * Wo + X) * Csrc + ch);
+    const bool ok = e < NV && Y >= 0 && Y < Ho && X >= 0 && X < Wo && ch < C;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? ((int64_t)Y * Wo + X) * Csrc + ch : 0));
+    stg[i] = ok ? v : uint4{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int e = tid + i * EW_THREADS;
+    if (e < NV) *reinterpret_cast<uint4*>(btile + (e / VC) * PITCH + (e % VC) * 16) = stg[i];
   }
   __syncthreads();
   for (int i = tid; i < UPB_T * UPB_T * VC; i += EW_THREADS) {
