@@ -19,7 +19,7 @@ FAMILIES = [
     ("maxpool2x2_fwd", r"maxpool_fwd_kernel"),
     ("upsample2x_fwd", r"up_fwd_tiled_kernel"),
     ("upsample2x_bwd", r"up_bwd_tiled_kernel"),
-    ("conv1x1_fwd", r"conv1x1_fwd_kernel"),
+    ("conv1x1_fwd", r"conv1x1_fwd_kernel|conv1x1_fwd_cv_kernel"),
     ("conv1x1_bwd", r"conv1x1_bwd_kernel"),
     ("loss_metrics_fwd", r"loss_metrics_kernel"),
     ("loss_bwd", r"loss_bwd_kernel"),
