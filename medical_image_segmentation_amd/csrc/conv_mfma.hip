@@ -970,7 +970,7 @@ template <typename T, int MTO, int NTI, int WCO, int WCI, int WK>
 __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x3_wgrad_mfma_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, int Ca, const T* __restrict__ dz, float* __restrict__ slab,
     int B, int H, int W, int Cin, int Cout, int n_ci_blocks, int tiles_x, int tiles_y, int n_tiles,
-    const float* __restrict__ affa, const float* __restrict__ affb) {
+    const float* __restrict__ affa, const float* __restrict__ affb, int nsplit, int nout) {
   constexpr int NTHR = 64 * WCO * WCI * WK;
   constexpr int G = Mf<T>::G;
   constexpr int TH = WgT<T>::TH;
@@ -990,7 +990,23 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid % WK, wci = (wid / WK) % WCI, wco = wid / (WK * WCI);
-  const int cib = blockIdx.y % n_ci_blocks, cob = blockIdx.y / n_ci_blocks;
+  // One-dimensional grid of nsplit * nout workgroups.  The nout (co, ci) blocks of one tile range
+  // read the same x and dz tiles; consecutive workgroup ids go round the 8 XCDs (each with its own
+  // L2), so with nsplit a multiple of 8 the blocks of a range are given ids 8 apart: same XCD, launched
+  // together, and the second reader of a cache line finds it in that L2.
+  int bx, by;
+  {
+    const int id = blockIdx.x;
+    if ((nsplit & 7) == 0) {
+      const int j = id >> 3;
+      by = j % nout;
+      bx = (j / nout) * 8 + (id & 7);
+    } else {
+      by = id % nout;
+      bx = id / nout;
+    }
+  }
+  const int cib = by % n_ci_blocks, cob = by / n_ci_blocks;
   const int ci0 = cib * CTI, co0 = cob * CTO;
   // two-tensor input [xa (Ca channels) | xb]: this workgroup's channel tile lies in one of them
   const bool sb = xb != nullptr && ci0 >= Ca;
@@ -1082,8 +1098,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   }
   // this workgroup's contiguous tile range (x fastest, then y, then image): coordinates advance
   // by carries, neighbouring halos overlap in the same CU's cache
-  const int nb_ = gridDim.x, q_ = n_tiles / nb_, r_ = n_tiles % nb_;
-  const int bx = blockIdx.x;
+  const int nb_ = nsplit, q_ = n_tiles / nb_, r_ = n_tiles % nb_;
   const int t_begin = bx * q_ + (bx < r_ ? bx : r_);
   const int t_count = q_ + (bx < r_ ? 1 : 0);
   TilePos cur;
@@ -1170,7 +1185,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   }
   if (wk == 0) {
     // lane: 4 consecutive co (rows 4*(lane>>4)+r) of one ci (col lane&15); slab [split][tap][ci][co]
-    float* sl = slab + (int64_t)blockIdx.x * 9 * Cin * Cout;
+    float* sl = slab + (int64_t)bx * 9 * Cin * Cout;
 #pragma unroll
     for (int t = 0; t < 9; t++)
 #pragma unroll
@@ -1269,6 +1284,7 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1) 
   if (ns > p.n_tiles) ns = p.n_tiles;
   if (ns > 1024) ns = 1024;
   if (ns < 1) ns = 1;
+  if (nout > 1 && ns >= 8) ns &= ~7;          // whole groups of 8: the kernel's XCD-aware id mapping
   p.nsplit = ns;
   const size_t tiles = (size_t)(TH + 2) * (WG_TW + 2) * padded_row_bytes(p.CTI * (int)sizeof(T)) + 16 +
                        (size_t)TH * WG_TW * padded_row_bytes(p.CTO * (int)sizeof(T)) + 16 + 2 * (size_t)p.CTI * 4;
@@ -1288,7 +1304,8 @@ int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, f
     return MIS_ERR_UNSUPPORTED;
   }
   float* slab = (float*)workspace;
-  dim3 grid(p.nsplit, p.n_co_blocks * p.n_ci_blocks);
+  const int nout_blocks = p.n_co_blocks * p.n_ci_blocks;
+  dim3 grid(p.nsplit * nout_blocks);
 #define WG_LAUNCH(MTO, NTI, WCO, WCI, WK)                                                                  \
   {                                                                                                        \
     auto kfn = conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK>;                                       \
@@ -1296,7 +1313,7 @@ int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, f
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
     kfn<<<grid, 64 * WCO * WCI * WK, p.lds, st>>>((const T*)in.xa, (const T*)in.xb, in.Ca, (const T*)dz, slab, B, \
                                                   H, W, Cin, Cout, p.n_ci_blocks, p.tiles_x, p.tiles_y,    \
-                                                  p.n_tiles, in.affa, in.affb);                            \
+                                                  p.n_tiles, in.affa, in.affb, p.nsplit, nout_blocks);     \
   }
   switch (p.cfg) {
     case 0: WG_LAUNCH(1, 1, 1, 1, 4); break;
