@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--h2d", action="store_true",
                     help="copy the batch from pinned host memory inside every step (PCIe-inclusive rate; not the "
                          "headline value, whose inputs are resident in HBM)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a HIP graph (single GPU; utils/graph_step.py) instead of issuing it "
+                         "from Python: same kernels, one host call per step")
     return ap.parse_args()
 
 
@@ -156,6 +159,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eager_step = step
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-GPU")
+        from medical_image_segmentation_amd.utils.graph_step import GraphedTrainStep
+
+        def loss_of(m, x, y):
+            logits = m(x)
+            ld = loss_fn(logits, y)
+            return ld["total_loss"], (ld, metric.confusion_counts(logits, y))
+
+        graphed = GraphedTrainStep(model, opt, loss_of, images, masks, max_norm=1.0, warmup=2)
+
+        def step():
+            if host is not None:
+                _, (ld, counts), _ = graphed(host[0], host[1])
+            else:
+                _, (ld, counts), _ = graphed(graphed.images, graphed.masks)
+            pending.append(counts)
+            return ld
+
     for _ in range(args.warmup):
         step()
     pending.clear()
@@ -173,6 +197,8 @@ def main():
     # host post-math of the metrics for the timed steps (outside the timed region: the counts
     # were produced inside it)
     from medical_image_segmentation_amd.utils.train_and_eval import _finish_metrics
+    if args.graph:
+        pending = pending[-1:]        # the graph's output tensors are overwritten by every replay
     met = _finish_metrics(metric, pending, 4) / max(len(pending), 1)
 
     roof = None
@@ -182,7 +208,7 @@ def main():
         if rank == 0:
             F_.PROFILE = {}
         for _ in range(3):
-            step()
+            eager_step()              # (graph mode too: the replayed kernels are these)
         torch.cuda.synchronize()
         if rank == 0:
             roof = F_.profile_summary(PEAK_HBM_GBS, PEAK_BF16_TFLOPS, steps=3)
@@ -200,7 +226,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic" + (" (copied from pinned host memory every step)" if args.h2d else ""),
             "config": {"workload": f"UNet(in=1,classes=4,base=32) train step, batch {B}/GPU, {S}x{S}, "
                                    f"Dice loss + confusion counts + clip + AdamW",
-                       "global_batch": B * world, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "issue": "hip graph replay" if args.graph else "eager"},
             "final_loss": round(loss_val, 6),
             "optimizer_table_builds": _optim.PLAN_BUILDS, "optimizer_table_uploads": _optim.PLAN_UPLOADS,
             "mean_dice": round(float(met[2, -1]), 6),

@@ -394,6 +394,17 @@ int mis_clip_adamw_step(const void* descs, const int* chunk_prefix, int n_tensor
                         int n_chunks, const void* workspace, float max_norm, double lr, double beta1, double beta2,
                         double eps, double weight_decay, int64_t step, int write_clipped_grads, float* total_norm,
                         mis_stream_t stream);
+/* The same update with its step-dependent constants read from device memory, for a launch that  */
+/* is captured once in a HIP graph and replayed every step (the reference has no counterpart: it */
+/* re-issues optimizer.step() from Python).  step_constants: device float[3] = (1-lr*wd,          */
+/* lr/(1-b1^t), sqrt(1-b2^t)); the host forms them with mis_adamw_step_constants (host-only, no   */
+/* GPU work: the same double arithmetic mis_clip_adamw_step uses) and copies them in before each  */
+/* replay.                                                                                       */
+void mis_adamw_step_constants(double lr, double beta1, double beta2, double weight_decay, int64_t step, float* out3);
+int mis_clip_adamw_step_dyn(const void* descs, const int* chunk_prefix, int n_tensors, int chunk_begin, int chunk_end,
+                            int n_chunks, const void* workspace, float max_norm, double beta1, double beta2, double eps,
+                            const float* step_constants, int write_clipped_grads, float* total_norm,
+                            mis_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,8 @@ PROTOTYPES = {
     "mis_clip_adamw_workspace_bytes": (_sz, [_i]),
     "mis_grad_sqsum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mis_clip_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _d, _d, _d, _d, _d, _i64, _i, _vp, _vp]),
+    "mis_adamw_step_constants": (None, [_d, _d, _d, _d, _i64, _vp]),
+    "mis_clip_adamw_step_dyn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _d, _d, _d, _vp, _i, _vp, _vp]),
     "mis_conv3x3_cat_supported": (_i, [_i] * 7),
     "mis_conv3x3_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_split_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -70,8 +70,14 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adamw_kernel(const Desc* __r
                                                                  float beta1, float omb1, float beta2, float omb2,
                                                                  float eps, float step_size,
                                                                  float bc2_sqrt, int write_grads,
-                                                                 float* __restrict__ total_norm_out) {
+                                                                 float* __restrict__ total_norm_out,
+                                                                 const float* __restrict__ dyn) {
   __shared__ double red[OPT_THREADS / 64];
+  if (dyn) {            // step-dependent constants from device memory (a captured launch replayed every step)
+    decay = dyn[0];
+    step_size = dyn[1];
+    bc2_sqrt = dyn[2];
+  }
   double acc = 0.0;
   for (int i = threadIdx.x; i < n_partials; i += OPT_THREADS) acc += partials[i];
   const double sq = block_sum_double(acc, red);
@@ -134,7 +140,29 @@ int mis_clip_adamw_step(const void* descs, const int* chunk_prefix, int n_tensor
   clip_adamw_kernel<<<chunk_end - chunk_begin, OPT_THREADS, 0, (hipStream_t)stream>>>(
       (const Desc*)descs, chunk_prefix, n_tensors, chunk_begin, (const double*)workspace, n_chunks, max_norm,
       (float)(1.0 - (double)lr * (double)weight_decay), (float)beta1, (float)(1.0 - b1d), (float)beta2, (float)(1.0 - b2d), (float)eps,
-      (float)((double)lr / bc1), (float)sqrt(bc2), write_clipped_grads, total_norm);
+      (float)((double)lr / bc1), (float)sqrt(bc2), write_clipped_grads, total_norm, nullptr);
+  MIS_CHECK_LAUNCH("clip_adamw_kernel");
+  return MIS_OK;
+}
+
+void mis_adamw_step_constants(double lr, double beta1, double beta2, double weight_decay, int64_t step, float* out3) {
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  out3[0] = (float)(1.0 - lr * weight_decay);
+  out3[1] = (float)(lr / bc1);
+  out3[2] = (float)sqrt(bc2);
+}
+
+int mis_clip_adamw_step_dyn(const void* descs, const int* chunk_prefix, int n_tensors, int chunk_begin, int chunk_end,
+                            int n_chunks, const void* workspace, float max_norm, double beta1, double beta2, double eps,
+                            const float* step_constants, int write_clipped_grads, float* total_norm,
+                            mis_stream_t stream) {
+  MIS_REQUIRE(descs && chunk_prefix && workspace && step_constants && n_tensors >= 1, "clip_adamw_step_dyn: null pointer");
+  MIS_REQUIRE(0 <= chunk_begin && chunk_begin < chunk_end && chunk_end <= n_chunks, "clip_adamw_step_dyn: bad chunk range");
+  MIS_REQUIRE(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., "clip_adamw_step_dyn: bad betas");
+  clip_adamw_kernel<<<chunk_end - chunk_begin, OPT_THREADS, 0, (hipStream_t)stream>>>(
+      (const Desc*)descs, chunk_prefix, n_tensors, chunk_begin, (const double*)workspace, n_chunks, max_norm, 1.f,
+      (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 0.f, 1.f, write_clipped_grads,
+      total_norm, step_constants);
   MIS_CHECK_LAUNCH("clip_adamw_kernel");
   return MIS_OK;
 }

@@ -223,3 +223,85 @@ def _clip_and_step_checked(optimizer, params, max_norm):
     f.step = float(steps[0] - 1)
     _FAST[id(optimizer)] = f
     return _launch(optimizer, f, max_norm)
+
+
+class CapturedStep:
+    """clip_grad_norm_ + AdamW.step() in a form that can sit inside a HIP graph: the launches take
+    everything that changes from step to step (learning rate, bias corrections) from a small
+    device buffer, so one capture serves every replay.
+
+    `launch()` is called once, inside the capture (the gradients exist by then; their addresses
+    are those of every replay).  Before each replay `prepare()` forms the step's constants on the
+    host — the same double arithmetic the eager path uses, so both give the same bits — and
+    copies them in; after it `advance()` moves torch's own step counters, which live on the host.
+    Pinned host buffers are private to this object: a captured copy re-reads them at every replay.
+    """
+
+    def __init__(self, optimizer, params, max_norm=1.0):
+        params = [p for p in params]
+        if _fast_path(optimizer, params) is None:
+            raise RuntimeError("CapturedStep needs an optimizer that has taken at least one fused eager step "
+                               "with these parameters (clip_and_step)")
+        self.optimizer, self.params, self.max_norm = optimizer, params, float(max_norm)
+        self.f = _FAST[id(optimizer)]
+        self.plan = _PLANS[id(optimizer)]
+        dev = self.f.groups[0][1][0].device
+        n_t, n_g = len(self.f.static), len(self.f.groups)
+        self.rows_host = torch.empty((n_t, 5), dtype=torch.int64).pin_memory()
+        self.descs = torch.empty((n_t, 5), dtype=torch.int64, device=dev)
+        # the host may run several steps ahead of the GPU: a small ring of pinned slots, each reused
+        # only after the copy that read it has completed
+        self.dyn_host = [torch.zeros((n_g, 4), dtype=torch.float32).pin_memory() for _ in range(8)]
+        self.dyn_done = [None] * 8
+        self.slot = 0
+        self.dyn = torch.zeros((n_g, 4), dtype=torch.float32, device=dev)
+        self.norm = None
+
+    def prepare(self):
+        """Host side of the next step: constants for step count + 1 and the current learning rates."""
+        step = int(self.f.step) + 1
+        i = self.slot
+        self.slot = (i + 1) % len(self.dyn_host)
+        if self.dyn_done[i] is not None:
+            self.dyn_done[i].synchronize()
+        host = self.dyn_host[i]
+        for k, (g, _) in enumerate(self.f.groups):
+            if not _group_ok(g):
+                raise RuntimeError("optimizer options changed after the capture")
+            b1, b2 = g["betas"]
+            query("mis_adamw_step_constants", float(g["lr"]), float(b1), float(b2), float(g["weight_decay"]), step,
+                  host[k].data_ptr())
+        self.dyn.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.dyn_done[i] = ev
+
+    def launch(self):
+        """The two launches (and the upload of the pointer rows) on the current, capturing stream."""
+        f, plan = self.f, self.plan
+        dev = self.descs.device
+        rows = [(sp, p.grad.data_ptr(), sm, sv, n)
+                for p, (sp, sm, sv, n) in zip((p for _, ps in f.groups for p in ps), f.static)]
+        self.rows_host.copy_(torch.tensor(rows, dtype=torch.int64))
+        self.descs.copy_(self.rows_host, non_blocking=True)
+        st = F_._stream()
+        ws = F_.workspace(plan.ws_bytes, dev)
+        self.norm = torch.empty((), dtype=torch.float32, device=dev)
+        n_t = len(rows)
+        call("mis_grad_sqsum", self.descs.data_ptr(), plan.prefix.data_ptr(), n_t, plan.n_chunks, ws.data_ptr(), st)
+        for k, ((g, ps), (c0, c1)) in enumerate(zip(f.groups, plan.group_chunks)):
+            b1, b2 = g["betas"]
+            call("mis_clip_adamw_step_dyn", self.descs.data_ptr(), plan.prefix.data_ptr(), n_t, c0, c1, plan.n_chunks,
+                 ws.data_ptr(), self.max_norm, float(b1), float(b2), float(g["eps"]), self.dyn[k].data_ptr(), 1,
+                 self.norm.data_ptr() if c0 == 0 else None, st)
+        return self.norm
+
+    def advance(self):
+        """Host bookkeeping after a replay: torch's step counters, tensor versions."""
+        f = self.f
+        torch._foreach_add_(f.step_tensors, 1)
+        f.step = float(int(f.step) + 1)
+        touched = []
+        for _, ps in f.groups:
+            touched += ps
+        torch._C._increment_version(touched)
