@@ -690,6 +690,9 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
   constexpr int G = Mf<T>::G;
   if (Cin % G != 0 || Cout % 4 != 0 || Cin < G) return false;
   if ((int64_t)Cin * Cout >= ((int64_t)1 << 26)) return false;      // packed image indices stay below 2^31
+  // one image of either tensor is addressed through a 32-bit buffer descriptor (byte offsets, and
+  // 0x7FFFFFFF means "out of range"): larger images take the direct kernels
+  if ((int64_t)H * W * (Cin > Cout ? Cin : Cout) * (int64_t)sizeof(T) >= ((int64_t)1 << 31) - (1 << 22)) return false;
   const int groups = Cin / G;
   if (groups <= 4) {
     p.CPG = groups;
@@ -1252,6 +1255,7 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1) 
   constexpr int G = Mf<T>::G;
   constexpr int TH = WgT<T>::TH;
   if (Cin % G != 0 || Cout % G != 0) return false;
+  if ((int64_t)H * W * (Cin > Cout ? Cin : Cout) * (int64_t)sizeof(T) >= ((int64_t)1 << 31) - (1 << 22)) return false;
   if (Cout >= 64 && Cin >= 64) { p.cfg = 4; p.CTO = 64; p.CTI = 64; }
   else if (Cout > 16 && Cin > 16) { p.cfg = 3; p.CTO = 32; p.CTI = 32; }
   else if (Cout > 16) { p.cfg = 1; p.CTO = 32; p.CTI = 16; }
