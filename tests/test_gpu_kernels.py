@@ -691,6 +691,63 @@ def test_bn_sums_fused_into_gradient_producer(F_, dtype, consumer):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16, 32), (1, 16, 64, 24, 40), (2, 3, 12, 8, 8)])
+@pytest.mark.parametrize("with_skip,with_noise", [(True, False), (False, False), (True, True)])
+def test_pool_backward_fused_with_bn_backward(F_, dtype, shape, with_skip, with_noise):
+    """conv+BN+ReLU -> max-pool (+skip, +Dropout2d): with the producer flag set the pooling backward
+    hands over a stand-in and the conv node forms dz from (z, pooled gradient, skip gradient) in one
+    kernel; no activation gradient is stored.  Same values as the two-kernel path: the activation
+    gradient is rounded to the storage type in registers exactly as the stored one would be."""
+    B, Ci, Co, H, W = shape
+    x = np.maximum(dg.hash_normalish((B, Ci, H, W), 1501), 0)
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm2d(Co).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(T(dg.hash_uniform((Co,), 1504, 0.5, 1.5)))
+        bn.bias.copy_(T(dg.hash_uniform((Co,), 1505, -0.2, 0.2)))
+    gy = dg.hash_normalish((B, Co, H // 2, W // 2), 1502)
+    gs = dg.hash_normalish((B, Co, H, W), 1503, std=0.3)
+    noise = None
+    if with_noise:
+        keep = (dg.hash_u64((B, Co, 1, 1), 1506) % np.uint64(4)) != 0
+        noise = torch.from_numpy(keep.astype(np.float32) / 0.75).to(DEV)
+    res, calls = [], []
+    orig = F_.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+
+    for fuse in (True, False):
+        F_.FUSE_POOL_DZ = fuse
+        F_.call = spy
+        calls.clear()
+        try:
+            for m in (conv, bn):
+                m.zero_grad()
+            xd = act(x, dtype).requires_grad_(True)
+            z, ss = F_.conv_bn_relu(xd, None, conv, bn, True)
+            y, skip = F_.PoolSkipFn.apply(z, ss, noise, True)
+            if with_skip:
+                torch.autograd.backward([y, skip], [act(gy, dtype), act(gs, dtype)])
+            else:
+                y.backward(act(gy, dtype))
+        finally:
+            F_.call = orig
+            F_.FUSE_POOL_DZ = False
+        assert ("mis_maxpool2x2_bwd_bn_dz" in calls) == fuse
+        assert ("mis_bn_relu_bwd_dz" in calls) == (not fuse)
+        res.append([xd.grad.float().clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), bn.weight.grad.clone(),
+                    bn.bias.grad.clone()])
+    tol = 2e-5 if dtype == torch.float32 else 2e-3
+    for k, (a, b) in enumerate(zip(*res)):
+        if k == 2:      # conv-bias gradient: analytically zero, compare against the scale of dbeta
+            assert float((a - b).abs().max()) <= 1e-2 * float(res[0][4].abs().max()) + 1e-5
+        else:
+            assert rel_err(a, b) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ch", [(8, 16, 32), (16, 64, 64), (32, 8, 16), (64, 128, 64)])
 def test_bn_sums_fused_into_data_gradient(F_, dtype, ch):
     """DoubleConv backward: the second conv's data-gradient kernel also accumulates the first

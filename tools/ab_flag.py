@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""A/B of a boolean switch of medical_image_segmentation_amd.functional inside one process:
+alternating blocks of timed bench-shaped steps.   python tools/ab_flag.py FUSE_POOL_DZ [batch]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from medical_image_segmentation_amd import functional as F_  # noqa: E402
+from medical_image_segmentation_amd.model.unet import UNet  # noqa: E402
+from medical_image_segmentation_amd.utils.loss_fn import diceloss  # noqa: E402
+from medical_image_segmentation_amd.utils.optim import clip_and_step  # noqa: E402
+
+flag = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+dev = torch.device("cuda", 0)
+m = UNet(1, 4, 0, base_channels=32, compute_dtype=torch.bfloat16).to(dev).train()
+opt = torch.optim.AdamW(m.parameters(), lr=8e-4, betas=(0.95, 0.999), weight_decay=1e-4)
+x = torch.randn(B, 1, 512, 512, device=dev)
+y = torch.randint(0, 4, (B, 512, 512), device=dev)
+loss_fn = diceloss(["a", "b", "c"])
+params = list(m.parameters())
+
+
+def step():
+    opt.zero_grad()
+    loss_fn(m(x), y)["total_loss"].backward()
+    clip_and_step(opt, params, 1.0)
+
+
+for value in (False, True, False, True, False, True):
+    setattr(F_, flag, value)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        step()
+    torch.cuda.synchronize()
+    print(f"{flag}={value} {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms/step", flush=True)
