@@ -286,7 +286,9 @@ int bwd_reduce_t(const void* z, const void* da, int64_t n_pix, int C, const floa
 }
 
 static inline int bwd_dz_grid(int64_t n, int C, int V) {
-  return grid_for_fixed_channels(ew_grid(n / V, EW_THREADS), C / V, 1024);
+  // two workgroups per CU, each thread streaming a long range, measured fastest (384: -10 %, 1024: -2 %,
+  // 2048: -6 %), and the conv-bias rows the weight-gradient reduction sums afterwards are fewer
+  return grid_for_fixed_channels(ew_grid(n / V, EW_THREADS), C / V, 512);
 }
 
 template <typename T>

@@ -603,7 +603,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   }
 }
 
-constexpr int C1_MAX_BLOCKS = 1024;
+constexpr int C1_MAX_BLOCKS = 2048;
 
 template <typename T, int CO>
 int conv1x1_fwd_t(const void* x, const float* x_aff, int64_t n_pix, int Cin, const float* w, const float* bias,

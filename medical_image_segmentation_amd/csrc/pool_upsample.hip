@@ -624,10 +624,9 @@ int pool_bwd(const void* x, const void* dy, const void* add, void* dx, int B, in
   float* partials = nullptr;
   if (bn_sums) {
     // fixed channel vector per thread; one partial row per workgroup
-    // few enough partial rows that the final reduction (rows x 2C floats) stays small
-    int cap = 32768 / C;
-    if (cap < 256) cap = 256;
-    if (cap > POOL_MAX_ROWS) cap = POOL_MAX_ROWS;
+    // (6 workgroups per CU measured best at the sizes this path is used for: 1024 -> 1536 rows took
+    // 8 % off the kernel, 2048+ gave it back in the row reduction)
+    const int cap = 1536;
     grid = grid_for_fixed_channels(grid, C / V, cap);
     const size_t red = (size_t)EW_THREADS * 2 * V * sizeof(float);
     if (red > lds) lds = red;

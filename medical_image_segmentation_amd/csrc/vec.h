@@ -75,7 +75,7 @@ static inline int pick_vec(int C, const void* a, const void* b = nullptr, const 
 
 static inline int ew_grid(int64_t work_items, int threads) {
   int64_t g = (work_items + threads - 1) / threads;
-  if (g > 256 * 16) g = 256 * 16;   // grid-stride beyond ~16 blocks per CU
+  if (g > 256 * 16) g = 256 * 16;   // grid-stride beyond ~16 blocks per CU (1024..8192 measure the same)
   if (g < 1) g = 1;
   return (int)g;
 }
