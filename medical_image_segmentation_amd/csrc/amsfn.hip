@@ -348,21 +348,33 @@ __global__ __launch_bounds__(TPB) void dw_compose_bwd_kernel(const float* __rest
                                                              const float* __restrict__ db, int Cout, int Cin,
                                                              float* __restrict__ dP, float* __restrict__ dD,
                                                              float* __restrict__ dbd) {
+  // dP: one thread per element (9 terms).  dD and dbd sum over Cout: 8 consecutive lanes share an
+  // element (lane j takes o = j, j+8, ...) and are summed on the DPP path, so the dependent chain is
+  // Cout/8 long instead of Cout.  TPB is a multiple of 8 and the grid-stride keeps lane groups whole.
   const int nP = Cout * Cin, nD = Cin * 9;
-  for (int e = blockIdx.x * TPB + threadIdx.x; e < nP + nD + Cin; e += gridDim.x * TPB) {
+  const int total = nP + 8 * (nD + Cin);
+  for (int e = blockIdx.x * TPB + threadIdx.x; e < total; e += gridDim.x * TPB) {
     float acc = 0.f;
     if (e < nP) {
       const int i = e % Cin, o = e / Cin;
       for (int t = 0; t < 9; t++) acc += dW[(o * Cin + i) * 9 + t] * D[i * 9 + t];
       dP[e] = acc + db[o] * bd[i];
-    } else if (e < nP + nD) {
-      const int f = e - nP, t = f % 9, i = f / 9;
-      for (int o = 0; o < Cout; o++) acc += dW[(o * Cin + i) * 9 + t] * P[o * Cin + i];
-      dD[f] = acc;
     } else {
-      const int i = e - nP - nD;
-      for (int o = 0; o < Cout; o++) acc += db[o] * P[o * Cin + i];
-      dbd[i] = acc;
+      const int g = (e - nP) >> 3, j = (e - nP) & 7;
+      if (g < nD) {
+        const int t = g % 9, i = g / 9;
+        for (int o = j; o < Cout; o += 8) acc += dW[(o * Cin + i) * 9 + t] * P[o * Cin + i];
+      } else {
+        const int i = g - nD;
+        for (int o = j; o < Cout; o += 8) acc += db[o] * P[o * Cin + i];
+      }
+      acc += dpp_move<0xB1>(acc);
+      acc += dpp_move<0x4E>(acc);
+      acc += dpp_move<0x141>(acc);
+      if (j == 0) {
+        if (g < nD) dD[g] = acc;
+        else dbd[g - nD] = acc;
+      }
     }
   }
 }
@@ -562,7 +574,7 @@ int mis_dwconv_compose_bwd(const float* P, const float* D, const float* bd, cons
                            int Cin, float* dP, float* dD, float* dbd, mis_stream_t stream) {
   MIS_REQUIRE(P && D && bd && dW && db && dP && dD && dbd, "dwconv_compose_bwd: null pointer");
   MIS_REQUIRE(Cout >= 1 && Cin >= 1 && (int64_t)Cout * Cin * 9 < (1 << 30), "dwconv_compose_bwd: bad shape");
-  dw_compose_bwd_kernel<<<ew_grid((int64_t)Cout * Cin + Cin * 10, TPB), TPB, 0, (hipStream_t)stream>>>(
+  dw_compose_bwd_kernel<<<ew_grid((int64_t)Cout * Cin + Cin * 80, TPB), TPB, 0, (hipStream_t)stream>>>(
       P, D, bd, dW, db, Cout, Cin, dP, dD, dbd);
   MIS_CHECK_LAUNCH("dw_compose_bwd_kernel");
   return MIS_OK;
