@@ -96,3 +96,22 @@ def test_graphed_step_rejects_other_shapes():
     step = GraphedTrainStep(m, o, lambda mm, a, b: (loss_fn(mm(a), b)["total_loss"], None), x, y, warmup=1)
     with pytest.raises(ValueError):
         step(x[:1], y[:1])
+
+
+def test_graphed_step_with_dropout_draws_new_masks():
+    """Dropout2d inside the captured step: torch's generator advances with every replay, so two
+    replays on the same batch drop different feature maps (different losses), and training mode
+    keeps working."""
+    from medical_image_segmentation_amd.model.unet import UNet
+    from medical_image_segmentation_amd.utils.graph_step import GraphedTrainStep
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    loss_fn = diceloss(["a", "b", "c"])
+    torch.manual_seed(5)
+    m = UNet(1, 4, 0.3, base_channels=8, compute_dtype=torch.float32)
+    m.load_state_dict({k: v.clone() for k, v in orc.make_state(1, 4, base=8, seed=53).items()})
+    m = m.to(DEV).train()
+    o = torch.optim.AdamW(m.parameters(), lr=0.0)            # lr 0: the weights stay, only the masks change
+    (x, y), = _batches(1, 2, 32)
+    step = GraphedTrainStep(m, o, lambda mm, a, b: (loss_fn(mm(a), b)["total_loss"], None), x, y, warmup=1)
+    losses = [float(step(x, y)[0]) for _ in range(4)]
+    assert all(np.isfinite(losses)) and len(set(losses)) > 1
