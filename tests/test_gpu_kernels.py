@@ -439,7 +439,8 @@ def test_double_conv_golden(F_, golden, name, c):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 32, 4, 16, 16), (1, 8, 9, 8, 24), (2, 16, 2, 8, 8)])
+@pytest.mark.parametrize("shape", [(2, 32, 4, 16, 16), (1, 8, 9, 8, 24), (2, 16, 2, 8, 8), (1, 64, 3, 8, 8),
+                                   (1, 128, 4, 8, 8)])      # 2..16 lanes per pixel in the forward
 @pytest.mark.parametrize("lazy", [False, True])
 def test_conv1x1(F_, dtype, shape, lazy):
     B, Ci, Co, H, W = shape
