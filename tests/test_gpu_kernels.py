@@ -522,7 +522,8 @@ def test_conv3x3_mfma_vs_direct_and_oracle(F_, dtype, shape, transposed, lazy):
 WGRAD_SHAPES = [  # B, Cin, Cout, H, W
     (2, 8, 32, 16, 32), (1, 16, 64, 32, 32), (1, 32, 16, 32, 64), (2, 64, 32, 16, 16), (1, 128, 64, 16, 32),
     (1, 64, 256, 16, 16), (1, 256, 512, 8, 8), (1, 512, 32, 16, 16), (2, 64, 8, 32, 32), (1, 24, 8, 20, 12),
-    (3, 8, 8, 4, 4), (1, 32, 128, 2, 2), (1, 8, 16, 9, 33), (2, 128, 8, 16, 16), (1, 16, 24, 18, 34)]
+    (3, 8, 8, 4, 4), (1, 32, 128, 2, 2), (1, 8, 16, 9, 33), (2, 128, 8, 16, 16), (1, 16, 24, 18, 34),
+    (1, 64, 32, 40, 96), (2, 128, 64, 24, 64)]      # uneven tile ranges over 8 K-splits, several (co, ci) blocks
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
