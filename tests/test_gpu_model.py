@@ -355,3 +355,51 @@ def test_weight_packer_tracks_updates():
             assert launches.count("mis_pack_conv3x3_weights_multi") == before
     finally:
         F_.call = orig
+
+
+def test_full_size_step_properties():
+    """The benchmark configuration itself (16 x 1 x 512^2, base 32), too large for the CPU oracle:
+    (i) no kernel on the path uses floating-point atomics, so two runs of the same step from the same
+    state are bit-identical — logits, loss, every gradient; (ii) bfloat16 and float32 compute modes
+    agree to the storage format's error (the bound measured on the oracle-sized cases); (iii) the
+    per-class confusion counts of the fused loss/metrics pass sum to the pixel count; (iv) three
+    steps of AdamW lower the loss."""
+    from medical_image_segmentation_amd.model.unet import UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    from medical_image_segmentation_amd.utils.metrics import Metrics
+    from medical_image_segmentation_amd.utils.optim import clip_and_step
+    B, S = 16, 512
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 1, S, S, generator=g).to(DEV)
+    y = torch.randint(0, 4, (B, S, S), generator=g).to(DEV)
+    state = {k: v.clone() for k, v in orc.make_state(1, 4, base=32, seed=61).items()}
+    loss_fn, metric = diceloss(["a", "b", "c"]), Metrics(["a", "b", "c"])
+
+    def run(dtype, steps=1):
+        m = UNet(1, 4, 0, base_channels=32, compute_dtype=dtype)
+        m.load_state_dict(state)
+        m = m.to(DEV).train()
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
+        out = []
+        for _ in range(steps):
+            opt.zero_grad()
+            logits = m(x)
+            ld = loss_fn(logits, y)
+            cm, status = metric.confusion_counts(logits, y)
+            ld["total_loss"].backward()
+            out.append((logits.detach().float().clone(), float(ld["total_loss"].detach()), cm.clone(),
+                        [p.grad.clone() for p in m.parameters()]))
+            clip_and_step(opt, list(m.parameters()), 1.0)
+        assert int(status) == 0
+        return out
+
+    a, b = run(torch.bfloat16)[0], run(torch.bfloat16)[0]
+    assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[2], b[2])
+    assert all(torch.equal(p, q) for p, q in zip(a[3], b[3]))
+    assert int(a[2].sum()) == B * S * S and torch.equal(a[2].sum(dim=2).sum(dim=0).cpu(),
+                                                          torch.bincount(y.reshape(-1).cpu(), minlength=4))
+    f = run(torch.float32, steps=3)
+    rel = float((a[0] - f[0][0]).norm() / f[0][0].norm())
+    assert rel < 6e-2, rel
+    assert abs(a[1] - f[0][1]) < 1e-2
+    assert f[2][1] < f[0][1]
