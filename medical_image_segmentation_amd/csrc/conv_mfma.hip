@@ -150,14 +150,36 @@ __global__ __launch_bounds__(256) void pack_w3x3_multi_kernel(const mis_pack_job
   int j = 0;
   while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].first_block) j++;
   const mis_pack_job jb = jobs[j];
-  const int64_t total = jb.total_fwd + jb.total_t;
-  for (int64_t i0 = (int64_t)((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x; i0 < total;
-       i0 += (int64_t)jb.n_blocks * 256) {
-    const bool second = i0 >= jb.total_fwd;
-    const int64_t i = second ? i0 - jb.total_fwd : i0;
-    T* out = (T*)(second ? jb.out_t : jb.out_fwd);
-    out[i] = pack_elem<T>(jb.w, jb.Cw_out, jb.Cw_in, second ? 1 : 0, second ? jb.cpg_t : jb.cpg_fwd,
-                          second ? jb.nt_t : jb.nt_fwd, i);
+  // one thread = one 16-byte fragment vector (G consecutive input channels of one (cout, tap)): the
+  // index arithmetic is paid once per vector, the G sources are a strided gather, the store is 16 bytes
+  constexpr int G = Mf<T>::G;
+  const unsigned vf = (unsigned)(jb.total_fwd / G), vt = (unsigned)(jb.total_t / G);
+  for (unsigned v0 = (unsigned)((int)blockIdx.x - jb.first_block) * 256u + threadIdx.x; v0 < vf + vt;
+       v0 += (unsigned)jb.n_blocks * 256u) {
+    const bool tr = v0 >= vf;
+    const unsigned v = tr ? v0 - vf : v0;
+    const int cpg = tr ? jb.cpg_t : jb.cpg_fwd, ntt = tr ? jb.nt_t : jb.nt_fwd;
+    const int NS = (9 * cpg + 3) / 4;
+    const int Cout = tr ? jb.Cw_in : jb.Cw_out;
+    const int l = (int)(v % 64u);
+    const unsigned q = v / 64u;
+    const int n = (int)(q % (unsigned)ntt);
+    const unsigned q2 = q / (unsigned)ntt;
+    const int s = (int)(q2 % (unsigned)NS), c = (int)(q2 / (unsigned)NS);
+    const int g = 4 * s + (l >> 4);
+    const int tap = g / cpg, cg = g % cpg;
+    const int co = 16 * n + (l & 15), ci0 = (c * cpg + cg) * G;
+    union { u32x4 u; T t[G]; } o;
+    if (tap < 9 && co < Cout) {
+      const float* src = tr ? jb.w + ((int64_t)ci0 * jb.Cw_in + co) * 9 + (8 - tap)
+                            : jb.w + ((int64_t)co * jb.Cw_in + ci0) * 9 + tap;
+      const int64_t stride = tr ? (int64_t)jb.Cw_in * 9 : 9;
+#pragma unroll
+      for (int j = 0; j < G; j++) o.t[j] = from_f32<T>(src[j * stride]);
+    } else {
+      o.u = u32x4{0u, 0u, 0u, 0u};
+    }
+    *reinterpret_cast<u32x4*>((T*)(tr ? jb.out_t : jb.out_fwd) + (int64_t)v * G) = o.u;
   }
 }
 
@@ -894,8 +916,10 @@ int conv3x3_mfma_pack_pair(const float* w, int Cw_out, int Cw_in, int dtype, voi
 int conv3x3_mfma_pack_job(const float* w, int Cw_out, int Cw_in, int dtype, void* out_fwd, void* out_t,
                           int first_block, mis_pack_job* job) {
   const PackGeom f = pack_geom(Cw_in, Cw_out, dtype), t = pack_geom(Cw_out, Cw_in, dtype);
-  int nb = cdiv(f.total + t.total, 256 * 4);          // >= 4 elements per thread
+  const int64_t G = dtype == MIS_BF16 ? Mf<bf16>::G : Mf<float>::G;
+  int nb = (int)cdiv((f.total + t.total) / G, (int64_t)256);      // one 16-byte vector per thread
   if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
   *job = mis_pack_job{w, out_fwd, out_t, f.total, t.total, Cw_out, Cw_in, f.CPG, f.nt_total, t.CPG, t.nt_total,
                       first_block, nb};
   return nb;
