@@ -3,7 +3,8 @@
 The reference is single-GPU (train.py:75-76 pins CUDA_VISIBLE_DEVICES=0); this is the new
 exchange step the sharded batch needs: the 74 parameter gradients (2.9 M float32 = 11.6 MB)
 are flattened into a few buckets in reverse layer order (out_conv, decoder4 ... encoder1, the
-order backward produces them) and each bucket is all-reduced (average) as soon as its last
+order backward produces them; the last-produced small tensors form a bucket of their own) and each
+bucket is all-reduced (average) as soon as its last
 gradient has been accumulated, on the process group's own stream, overlapping the rest of
 the backward pass.  Per-peer messages are bucket/world bytes over the xGMI mesh, i.e.
 latency-bound, hence few large buckets.
@@ -16,7 +17,7 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, n_buckets=3, process_group=None):
+    def __init__(self, model, n_buckets=3, process_group=None, tail_numel=65536):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # RCCL averages in the collective; other backends (gloo) only sum
@@ -35,6 +36,20 @@ class GradSync:
                 cur, cur_n = [], 0
         if cur:
             self.buckets.append(cur)
+        # The last bucket's exchange cannot overlap anything: it starts when the first layer's gradient
+        # is done, i.e. when backward ends.  The parameters produced last (the full-resolution encoder
+        # levels, a few thousand values whose backward takes a fifth of the step) go alone, so what is
+        # exposed is one latency-bound message instead of the whole last third of the model.
+        last = self.buckets[-1]
+        tail, n_tail = [], 0
+        for p in reversed(last):
+            if n_tail + p.numel() > tail_numel:
+                break
+            tail.insert(0, p)
+            n_tail += p.numel()
+        if tail and len(tail) < len(last):
+            self.buckets[-1] = last[:len(last) - len(tail)]
+            self.buckets.append(tail)
         self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
                      for b in self.buckets]
         self.bucket_of = {}
