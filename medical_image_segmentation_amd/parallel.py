@@ -88,7 +88,7 @@ class GradSync:
             self._launch(bi)
 
     def finish_step(self):
-        """Wait for the buckets and scatter the averaged values back into p.grad."""
+        """Wait for the buckets; afterwards every p.grad holds the averaged gradient."""
         for bi, b in enumerate(self.buckets):
             if self.ready[bi] != len(b):          # a parameter received no gradient this step
                 for p in b:
@@ -101,8 +101,10 @@ class GradSync:
             if self.world > 1 and not self.avg_in_collective:
                 flat.div_(self.world)             # gloo has no AVG
             if self.world > 1:
-                views = flat.split([p.numel() for p in b])
-                torch._foreach_copy_([p.grad.reshape(-1) for p in b], list(views))
+                # the averaged values stay where they are: each p.grad becomes a view of the bucket (no
+                # copy back; the optimizer's pointer table then repeats from step to step)
+                for p, v in zip(b, flat.split([p.numel() for p in b])):
+                    p.grad = v.view_as(p)
 
     def remove(self):
         for h in self._hooks:
