@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--h2d", action="store_true",
                     help="copy the batch from pinned host memory inside every step (PCIe-inclusive rate; not the "
                          "headline value, whose inputs are resident in HBM)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal of the multi-GPU code path on one GPU: RCCL group of one rank, gradient exchange, "
+                         "barriers and the max-over-ranks timing all run (the value is a single-GPU value)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a HIP graph (single GPU; utils/graph_step.py) instead of issuing it "
                          "from Python: same kernels, one host call per step")
@@ -106,9 +109,18 @@ def main():
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    stdout_fd = None
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # stdout carries the one JSON line and nothing else: RCCL prints its version banner (NCCL_DEBUG=VERSION)
+        # straight to file descriptor 1 when the communicator is created, so descriptor 1 points at stderr until
+        # the line is printed
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from medical_image_segmentation_amd import _lib, functional as F_
     _lib.load()
@@ -125,8 +137,8 @@ def main():
     model = UNet(1, 4, 0, base_channels=32, compute_dtype=cdt).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=8e-4, betas=(0.95, 0.999), weight_decay=1e-4)
     sync = None
-    if world > 1:
-        sync = GradSync(model)
+    if dist_on:
+        sync = GradSync(model, always_reduce=True)
         sync.broadcast_parameters()
     loss_fn, metric = diceloss(names), Metrics(names)
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
@@ -155,7 +167,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,7 +201,7 @@ def main():
         ld = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -237,8 +249,11 @@ def main():
             out["kernels"] = roof["kernels"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(S, args.cpu_threads)
-        print(json.dumps(out))
-    if world > 1:
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
+        print(json.dumps(out), flush=True)
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -17,9 +17,11 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, n_buckets=3, process_group=None, tail_numel=65536):
+    def __init__(self, model, n_buckets=3, process_group=None, tail_numel=65536, always_reduce=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # always_reduce: run the collectives even in a group of one (exercises the whole path on one GPU)
+        self.active = self.world > 1 or (always_reduce and dist.is_initialized())
         # RCCL averages in the collective; other backends (gloo) only sum
         self.avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         params = [p for p in model.parameters() if p.requires_grad]
@@ -75,9 +77,13 @@ class GradSync:
 
     def _launch(self, bi):
         b, flat = self.buckets[bi], self.flat[bi]
-        views = flat.split([p.numel() for p in b])
-        torch._foreach_copy_(list(views), [p.grad.reshape(-1) for p in b])
-        if self.world > 1:
+        grads = [p.grad.reshape(-1) for p in b]
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        if not any(lo <= g.data_ptr() < hi for g in grads):
+            torch.cat(grads, out=flat)            # one batched copy launch for the whole bucket
+        else:                                     # gradients accumulated into last step's bucket views
+            torch._foreach_copy_(list(flat.split([p.numel() for p in b])), grads)
+        if self.active:
             self.handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM,
                                                group=self.group, async_op=True)
 
@@ -98,9 +104,9 @@ class GradSync:
             if self.handles[bi] is not None:
                 self.handles[bi].wait()
             flat = self.flat[bi]
-            if self.world > 1 and not self.avg_in_collective:
+            if self.active and not self.avg_in_collective:
                 flat.div_(self.world)             # gloo has no AVG
-            if self.world > 1:
+            if self.active:
                 # the averaged values stay where they are: each p.grad becomes a view of the bucket (no
                 # copy back; the optimizer's pointer table then repeats from step to step)
                 for p, v in zip(b, flat.split([p.numel() for p in b])):
