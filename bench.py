@@ -18,6 +18,8 @@ Extra objects on the line:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -100,13 +102,46 @@ def pmc_traffic(roof, B, S, dtype):
         roof["traffic_unit"] = "bytes per kernel launch (PMC, %s)" % os.path.basename(files[-1])
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started on its own (no launcher): this process has not touched
+    the GPU; it starts one child per GPU with the launcher's environment (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR/PORT on loopback), passes rank 0's stdout (the one JSON line) through,
+    sends the other ranks' stdout to stderr, and exits non-zero if any rank failed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, live = 0, dict(enumerate(procs))
+    while live:
+        time.sleep(0.1)
+        for r, p in list(live.items()):
+            c = p.poll()
+            if c is None:
+                continue
+            del live[r]
+            if c != 0 and rc == 0:
+                # the other ranks would wait for this one in their next collective for ever
+                print(f"bench.py: rank {r} exited with status {c}; stopping the other ranks", file=sys.stderr)
+                rc = c if c > 0 else 1
+                for q in live.values():
+                    q.terminate()
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_on = world > 1 or args.force_dist

@@ -123,21 +123,6 @@ size_t mis_maxpool2x2_bwd_workspace_bytes(int C);
 int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const float* noise, const void* dy, const void* dx_add,
                        int dtype, int B, int H, int W, int C, void* dx, float* bn_sums, void* workspace,
                        mis_stream_t stream);
-/* The same backward fused with the BatchNorm(train)+ReLU backward of x's producer */
-/* (model/utils/modules.py:86-94 under autograd): with dx == NULL, mis_maxpool2x2_bwd */
-/* only produces bn_sums; mis_maxpool2x2_bwd_bn_dz then forms the activation gradient */
-/* again in registers (rounded to the storage type, as it would have been stored) and */
-/* writes dz = gamma*rstd*(dy*mask - sum(dy)/n - xhat*sum(dy*xhat)/n) directly — the  */
-/* result of mis_maxpool2x2_bwd + mis_bn_relu_bwd_dz without the activation gradient  */
-/* ever reaching memory.  x_affine4 = [4][C] (scale, shift, mean, rstd); dbias         */
-/* (nullable) = sum(dz) per channel; dbias == workspace leaves the per-workgroup rows  */
-/* [mis_maxpool2x2_bwd_bn_dz_rows][C] un-reduced in the workspace (same convention as  */
-/* mis_bn_relu_bwd_dz; workspace of mis_maxpool2x2_bwd_workspace_bytes).               */
-int mis_maxpool2x2_bwd_bn_dz_rows(int dtype, int B, int H, int W, int C);
-int mis_maxpool2x2_bwd_bn_dz(const void* x, const float* x_affine4, const float* noise, const void* dy,
-                             const void* dx_add, int dtype, int B, int H, int W, int C, const float* gamma,
-                             const float* beta, const float* bn_sums, void* dz, float* dbias, void* workspace,
-                             mis_stream_t stream);
 /* out[b][2h][2w][0:Cup] = bilinear(low), out[...][Cup:Cup+Cskip] = skip.        */
 int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const float* low_noise, const void* skip,
                            const float* skip_affine, int dtype, int B, int h, int w, int Cup, int Cskip, void* out,

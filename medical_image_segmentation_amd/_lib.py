@@ -31,8 +31,6 @@ PROTOTYPES = {
     "mis_maxpool2x2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_maxpool2x2_bwd_workspace_bytes": (_sz, [_i]),
     "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "mis_maxpool2x2_bwd_bn_dz_rows": (_i, [_i, _i, _i, _i, _i]),
-    "mis_maxpool2x2_bwd_bn_dz": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_upsample2x_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_upsample2x_cat_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mis_conv3x3_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),

@@ -187,98 +187,6 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const T* __rest
   }
 }
 
-// The pooling backward and the BatchNorm+ReLU backward of the pooled tensor's producer in one
-// pass: the gradient of the activation (routed pooled gradient + skip gradient) is formed in
-// registers exactly as above — rounded to T, as it would have been stored — and goes straight into
-//     dz = gamma*rstd*(dy*mask - sum(dy)/n - xhat*sum(dy*xhat)/n),
-// with the two sums from a preceding sums-only launch of the kernel above.  The activation
-// gradient is never written or re-read.  `aff4` is [4][C] (scale, shift, mean, rstd);
-// `dz_partials` (optional) receives one row [C] of sum(dz) per workgroup (the conv-bias gradient).
-template <typename T, int V>
-__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_bn_dz_kernel(
-    const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, T* __restrict__ dz, int B, int H,
-    int W, int C, const float* __restrict__ aff4, const float* __restrict__ noise, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ sums, float inv_n, float* __restrict__ dz_partials) {
-  extern __shared__ float red[];              // [256][V] reduction scratch
-  const int Ho = H >> 1, Wo = W >> 1, CV = C / V;
-  const int64_t total = (int64_t)B * Ho * Wo * CV;
-  const int64_t i0 = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
-  const int c0 = (int)(i0 % CV) * V;          // fixed for this thread (the grid is sized for that)
-  float sc[V], sh[V], mean[V], rstd[V], gam[V], bet[V], m1[V], m2[V], bsum[V];
-#pragma unroll
-  for (int k = 0; k < V; k++) {
-    sc[k] = aff4[c0 + k];
-    sh[k] = aff4[C + c0 + k];
-    mean[k] = aff4[2 * C + c0 + k];
-    rstd[k] = aff4[3 * C + c0 + k];
-    gam[k] = gamma[c0 + k];
-    bet[k] = beta[c0 + k];
-    m1[k] = sums[c0 + k] * inv_n;
-    m2[k] = sums[C + c0 + k] * inv_n;
-    bsum[k] = 0.f;
-  }
-  for (int64_t i = i0; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
-    int64_t p = i / CV;
-    const int xo = (int)(p % Wo);
-    p /= Wo;
-    const int yo = (int)(p % Ho);
-    const int b = (int)(p / Ho);
-    const int64_t off = (((int64_t)b * H + 2 * yo) * W + 2 * xo) * C + c0;
-    const int64_t offs[4] = {off, off + C, off + (int64_t)W * C, off + (int64_t)W * C + C};
-    float zr[4][V], g[V], a4[4][V], o[4][V];
-#pragma unroll
-    for (int j = 0; j < 4; j++) vload<T, V>(x + offs[j], zr[j]);
-    vload<T, V>(dy + i * V, g);
-    if (add) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) vload<T, V>(add + offs[j], a4[j]);
-    }
-    if (noise) {
-#pragma unroll
-      for (int k = 0; k < V; k++) g[k] = to_f32(from_f32<T>(g[k] * noise[(int64_t)b * C + c0 + k]));
-    }
-#pragma unroll
-    for (int k = 0; k < V; k++) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = fmaxf(zr[j][k] * sc[k] + sh[k], 0.f);
-      float mm = v[0];
-      int am = 0;
-#pragma unroll
-      for (int j = 1; j < 4; j++) {
-        const bool take = (v[j] > mm) || (v[j] != v[j]);
-        mm = take ? v[j] : mm;
-        am = take ? j : am;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float da = (am == j) ? g[k] : 0.f;
-        if (add) da += a4[j][k];
-        da = to_f32(from_f32<T>(da));                       // the stored activation gradient
-        const float xh = (zr[j][k] - mean[k]) * rstd[k];
-        const float y = xh * gam[k] + bet[k];
-        const float d = (y > 0.f) ? da : 0.f;
-        o[j][k] = gam[k] * rstd[k] * (d - m1[k] - xh * m2[k]);
-        bsum[k] += to_f32(from_f32<T>(o[j][k]));
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) vstore<T, V>(dz + offs[j], o[j]);
-  }
-  if (dz_partials) {
-#pragma unroll
-    for (int k = 0; k < V; k++) red[threadIdx.x * V + k] = bsum[k];
-    __syncthreads();
-    const int base = (int)(((int64_t)blockIdx.x * EW_THREADS) % CV);
-    for (int j = threadIdx.x; j < C; j += EW_THREADS) {
-      const int cv = j / V, k = j % V;
-      float acc = 0.f;
-      for (int t = (cv - base + CV) % CV; t < EW_THREADS; t += CV) acc += red[t * V + k];
-      dz_partials[(int64_t)blockIdx.x * C + j] = acc;
-    }
-  }
-}
-
 // align_corners=True source coordinate, computed as torch does (float scale, float product).
 __device__ __forceinline__ void up_taps(int dst, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
   const float src = scale * (float)dst;
@@ -642,33 +550,6 @@ int pool_bwd(const void* x, const void* dy, const void* add, void* dx, int B, in
   return 0;
 }
 
-static inline int pool_dz_grid(int64_t n_pooled, int C, int V) {
-  return grid_for_fixed_channels(ew_grid(n_pooled / V, EW_THREADS), C / V, POOL_MAX_ROWS);
-}
-
-template <typename T>
-int pool_bwd_bn_dz(const void* x, const void* dy, const void* add, void* dz, int B, int H, int W, int C,
-                   const float* aff4, const float* noise, const float* gamma, const float* beta, const float* sums,
-                   float* dbias, void* ws, hipStream_t st) {
-  constexpr int N = VecOf<T>::N;
-  const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
-  const bool vec = pick_vec<T>(C, x, dy, dz, add) == N;
-  const int V = vec ? N : 1;
-  const int grid = pool_dz_grid(n, C, V);
-  const size_t lds = (size_t)EW_THREADS * V * sizeof(float);
-  const float inv_n = (float)(1.0 / ((double)B * H * W));
-  float* partials = dbias ? (float*)ws : nullptr;
-  if (vec)
-    maxpool_bwd_bn_dz_kernel<T, N><<<grid, EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)add, (T*)dz, B, H,
-                                                                   W, C, aff4, noise, gamma, beta, sums, inv_n, partials);
-  else
-    maxpool_bwd_bn_dz_kernel<T, 1><<<grid, EW_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)add, (T*)dz, B, H,
-                                                                   W, C, aff4, noise, gamma, beta, sums, inv_n, partials);
-  // dbias == workspace: the caller takes the partial rows [grid][C] as they are
-  if (dbias && dbias != partials) launch_reduce_partials(partials, grid, C, dbias, st);
-  return 0;
-}
-
 inline float up_scale(int n_in) { return (2 * n_in > 1) ? (float)(n_in - 1) / (float)(2 * n_in - 1) : 0.f; }
 
 template <typename T>
@@ -777,36 +658,6 @@ int mis_maxpool2x2_bwd(const void* x, const float* x_affine, const float* noise,
   else if (dtype == MIS_BF16) pool_bwd<bf16>(x, dy, dx_add, dx, B, H, W, C, x_affine, noise, bn_sums, workspace, (hipStream_t)stream);
   else MIS_REQUIRE(false, "maxpool2x2_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("maxpool_bwd_kernel");
-  return MIS_OK;
-}
-
-int mis_maxpool2x2_bwd_bn_dz_rows(int dtype, int B, int H, int W, int C) {
-  if (B < 1 || H < 2 || W < 2 || C < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
-  const int N = dtype == MIS_F32 ? VecOf<float>::N : VecOf<bf16>::N;
-  const int V = (C % N == 0) ? N : 1;
-  return pool_dz_grid((int64_t)B * (H / 2) * (W / 2) * C, C, V);
-}
-
-int mis_maxpool2x2_bwd_bn_dz(const void* x, const float* x_affine4, const float* noise, const void* dy,
-                             const void* dx_add, int dtype, int B, int H, int W, int C, const float* gamma,
-                             const float* beta, const float* bn_sums, void* dz, float* dbias, void* workspace,
-                             mis_stream_t stream) {
-  MIS_REQUIRE(x && x_affine4 && dy && gamma && beta && bn_sums && dz, "maxpool2x2_bwd_bn_dz: null pointer");
-  MIS_REQUIRE(!dbias || workspace, "maxpool2x2_bwd_bn_dz: dbias requested without a workspace");
-  MIS_REQUIRE(B >= 1 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
-              "maxpool2x2_bwd_bn_dz: H and W must be even and >= 2 (got %dx%d)", H, W);
-  MIS_REQUIRE(C <= 2048, "maxpool2x2_bwd_bn_dz: C too large");
-  MIS_REQUIRE((const void*)dbias != workspace ||
-                  ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dz | (uintptr_t)dx_add) & 15) == 0),
-              "maxpool2x2_bwd_bn_dz: partial rows need 16-byte aligned tensors");
-  if (dtype == MIS_F32)
-    pool_bwd_bn_dz<float>(x, dy, dx_add, dz, B, H, W, C, x_affine4, noise, gamma, beta, bn_sums, dbias, workspace,
-                          (hipStream_t)stream);
-  else if (dtype == MIS_BF16)
-    pool_bwd_bn_dz<bf16>(x, dy, dx_add, dz, B, H, W, C, x_affine4, noise, gamma, beta, bn_sums, dbias, workspace,
-                         (hipStream_t)stream);
-  else MIS_REQUIRE(false, "maxpool2x2_bwd_bn_dz: bad dtype %d", dtype);
-  MIS_CHECK_LAUNCH("maxpool_bwd_bn_dz_kernel");
   return MIS_OK;
 }
 

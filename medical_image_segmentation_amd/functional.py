@@ -78,6 +78,27 @@ def workspace(nbytes, device):
     return buf
 
 
+class private_workspaces:
+    """`with private_workspaces() as held:` — scratch buffers requested inside the block are fresh
+    ones that the cache forgets again on exit (`held` keeps them alive for the caller).  For graph
+    capture: the captured kernels' scratch then comes from the graph's own pool and belongs to the
+    captured object only — eager launches that later run on a stream with the same handle, or a
+    second capture, get buffers of their own, and a captured kernel never points into a cached
+    buffer that a later, larger request would replace and free."""
+
+    def __enter__(self):
+        self._saved = dict(_WS)
+        _WS.clear()
+        self.held = {}
+        return self.held
+
+    def __exit__(self, *exc):
+        self.held.update(_WS)
+        _WS.clear()
+        _WS.update(self._saved)
+        return False
+
+
 # ---------------------------------------------------------------------------
 # optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
 # ---------------------------------------------------------------------------
@@ -338,26 +359,10 @@ def take_bn_sums(da, z):
     tag = getattr(da, "_mis_bn_sums", None)
     if tag is None:
         return None
-    sums, zp, zv, dp = tag
-    if zp != z.data_ptr() or zv != z._version or dp != da.data_ptr():
+    sums, zp, zv, dp, dv = tag
+    if zp != z.data_ptr() or zv != z._version or dp != da.data_ptr() or dv != da._version:
         return None
     return sums
-
-
-# Pooling backward fused with the producer's BatchNorm+ReLU backward (no stored activation gradient):
-# 12 % fewer bytes on the encoder levels, but both passes then carry the window arithmetic and run at
-# ~3.1 TB/s instead of 4.6: measured 4.86 vs 4.84 ms per step, so it is off by default.
-FUSE_POOL_DZ = False
-
-
-def pool_grad_placeholder(x, dy, dskip, noise):
-    """Stand-in for the gradient of the lazy activation `x` that `PoolSkipFn.backward` hands to the
-    conv+BN+ReLU node that produced x: it has x's shape but no memory of its own (a 0-d tensor
-    expanded) and carries the pieces (pooled gradient, skip gradient, dropout multipliers) from
-    which that node's backward forms dz in one fused pass.  Only that node may receive it."""
-    ph = torch.empty((), dtype=x.dtype, device=x.device).expand(x.shape)
-    ph._mis_pool_grad = (dy, dskip, noise, x.data_ptr(), x._version)
-    return ph
 
 
 BN_SUMS_MIN_NUMEL = 15_000_000   # below this the layer's own small reduction pass is as cheap (measured on the full
@@ -453,25 +458,10 @@ class ConvBnReluFn(torch.autograd.Function):
         Cout, Cin = weight.shape[0], weight.shape[1]
         n_pix = B * H * W
         st = _stream()
-        pool = getattr(da, "_mis_pool_grad", None)
-        if pool is not None:
-            # the consumer was a max-pool (+ skip): `da` is a stand-in, the gradient is formed in registers
-            p_dy, p_dskip, p_noise, zp, zv = pool
-            if zp != z.data_ptr() or zv != z._version:
-                raise RuntimeError("pooling-gradient stand-in reached a node that did not produce the pooled tensor")
-            p_dy = to_act(p_dy, x.dtype)
-            p_dskip = to_act(p_dskip, x.dtype) if p_dskip is not None else None
-            sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
-            pws = workspace(query("mis_maxpool2x2_bwd_workspace_bytes", Cout), x.device)
-            nb = (z.numel() + p_dy.numel() + (z.numel() if p_dskip is not None else 0)) * z.element_size()
-            with _prof("maxpool2x2_bwd", 0, nb):
-                call("mis_maxpool2x2_bwd", z.data_ptr(), ss.data_ptr(), _p(p_noise), p_dy.data_ptr(), _p(p_dskip),
-                     _dt(x), B, H, W, Cout, None, sums.data_ptr(), pws.data_ptr(), st)
-        else:
-            # (sum dy, sum dy*xhat): already produced by the kernel that wrote `da` when that kernel had
-            # both z and da in registers (max-pool backward, 1x1-conv backward), else one pass over (z, da)
-            sums = take_bn_sums(da, z)
-            da = to_act(da, x.dtype)
+        # (sum dy, sum dy*xhat): already produced by the kernel that wrote `da` when that kernel had
+        # both z and da in registers (max-pool backward, 1x1-conv backward), else one pass over (z, da)
+        sums = take_bn_sums(da, z)
+        da = to_act(da, x.dtype)
         ws = workspace(query("mis_bn_relu_bwd_workspace_bytes", n_pix, Cout), x.device)
         if sums is None:
             sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
@@ -489,25 +479,16 @@ class ConvBnReluFn(torch.autograd.Function):
         # shared workspace is overwritten by the weight-gradient slabs); else they are reduced here.
         dbias = rows = None
         dz_ws = ws
-        if pool is not None:
-            dz_ws = pws
         if want_db and want_dw:
-            n_rows = (query("mis_maxpool2x2_bwd_bn_dz_rows", _dt(x), B, H, W, Cout) if pool is not None
-                      else query("mis_bn_relu_bwd_dz_rows", _dt(x), n_pix, Cout))
+            n_rows = query("mis_bn_relu_bwd_dz_rows", _dt(x), n_pix, Cout)
             rows = torch.empty((n_rows, Cout), dtype=torch.float32, device=x.device)
             dz_ws = rows
         elif want_db:
             dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
-        if pool is not None:
-            with _prof("bn_relu_bwd_dz", 0, nb + z.numel() * z.element_size()):
-                call("mis_maxpool2x2_bwd_bn_dz", z.data_ptr(), ss.data_ptr(), _p(p_noise), p_dy.data_ptr(), _p(p_dskip),
-                     _dt(x), B, H, W, Cout, gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
-                     rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
-        else:
-            with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
-                call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
-                     gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
-                     rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
+        with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
+            call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
+                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
+                 rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
         dx = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
             wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
@@ -631,25 +612,18 @@ class PoolSkipFn(torch.autograd.Function):
     once and sums them inside the pooling backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, x_ss, noise=None, from_conv_bn_relu=False):
-        # from_conv_bn_relu: (x, x_ss) is handed over directly by the conv+BN+ReLU node that produced
-        # it and has no other consumer; the backward may then leave the gradient to that node's
-        # fused kernel instead of writing it out (see pool_grad_placeholder)
+    def forward(ctx, x, x_ss, noise=None):
         y = _maxpool_fwd(x, x_ss, noise)
         ctx.save_for_backward(x, x_ss, noise)
         ctx.set_materialize_grads(False)
-        ctx.fuse = bool(from_conv_bn_relu)
         return y, x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dskip):
         x, x_ss, noise = ctx.saved_tensors
         if dy is None:
-            return dskip, None, None, None
-        if (ctx.fuse and FUSE_POOL_DZ and x_ss is not None and x_ss.dim() == 2
-                and x_ss.shape[0] == 4 and not torch.is_grad_enabled() and x.shape[1] <= 2048):
-            return pool_grad_placeholder(x, dy, dskip, noise), None, None, None
-        return _maxpool_bwd(x, x_ss, dy, dskip, noise), None, None, None
+            return dskip, None, None
+        return _maxpool_bwd(x, x_ss, dy, dskip, noise), None, None
 
 
 class UpsampleCatFn(torch.autograd.Function):
@@ -949,12 +923,28 @@ LOSS_DICE, LOSS_IOU = 0, 1
 
 class DiceLossFn(torch.autograd.Function):
     """losses[C] = (per-foreground-class Dice — or IoU, `kind` — losses..., total) and optionally
-    the CE map."""
+    the CE map.
+
+    `group` (a torch.distributed process group, or True for the default group): GLOBAL-batch
+    loss of a data-parallel run.  The reference pools its three sums over the whole batch before
+    forming the ratio (utils/loss_fn.py:79-80), so the mean of per-shard losses is a different
+    number; here the [3, C] partial sums of all ranks are added (one all-reduce of 3*C floats)
+    between the fused pass and the ratio, every rank returns the same global loss, and the
+    backward uses the global sums.  Each rank then holds the gradient of the global loss with
+    respect to ITS logits; a gradient exchange that AVERAGES over ranks (GradSync) would return
+    1/world of the true parameter gradient, so the backward scales by the world size."""
 
     @staticmethod
-    def forward(ctx, logits, target, smooth, want_ce, kind=LOSS_DICE):
+    def forward(ctx, logits, target, smooth, want_ce, kind=LOSS_DICE, group=None):
         sums, ce, cm, status, lg, tg = loss_metrics_raw(logits, target, True, want_ce, True)
         Cc = lg.shape[1]
+        ctx.grad_scale = 1.0
+        if group is not None:
+            import torch.distributed as dist
+            pg = None if group is True else group
+            if dist.is_initialized() and dist.get_world_size(pg) > 1:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=pg)
+                ctx.grad_scale = float(dist.get_world_size(pg))
         losses = torch.empty(Cc, dtype=torch.float32, device=lg.device)
         call("mis_dice_from_sums", sums.data_ptr(), Cc, smooth, kind, losses.data_ptr(), _stream())
         ctx.save_for_backward(lg, tg, sums)
@@ -975,6 +965,8 @@ class DiceLossFn(torch.autograd.Function):
         B, Cc, H, W = lg.shape
         _, sb, sc, sp = _logit_strides(lg)
         w = (dlosses if dlosses is not None else torch.zeros(Cc, device=lg.device)).to(torch.float32).contiguous()
+        if ctx.grad_scale != 1.0:
+            w = w * ctx.grad_scale
         dce_p = None
         if ctx.has_ce and dce is not None:
             dce = dce.to(torch.float32).contiguous()
@@ -985,4 +977,4 @@ class DiceLossFn(torch.autograd.Function):
                  w.data_ptr(), ctx.smooth, ctx.kind, dce_p, dlogits.data_ptr(), _stream())
         if dlogits.dtype != ctx.in_dtype:
             dlogits = dlogits.to(ctx.in_dtype)
-        return dlogits, None, None, None, None
+        return dlogits, None, None, None, None, None

@@ -58,20 +58,19 @@ class UNet(nn.Module):
         self._pack_weights(x.dtype)
         # every DoubleConv output stays lazy (z, ss): pool, upsample+concat, the next conv and the
         # 1x1 head apply its BatchNorm affine + ReLU while loading it.  `down` returns the pooled
-        # tensor and the skip alias of its input, so both gradients meet in one kernel (True: the
-        # input comes straight from its conv+BN+ReLU node, whose backward may fuse that kernel).
+        # tensor and the skip alias of its input, so both gradients meet in one kernel.
         # Dropout2d (identity at p == 0 / eval: no noise tensor, no extra work) is one multiplier per
         # (sample, channel): the kernel that consumes the dropped tensor's source applies it — the
         # pooling for the encoder dropouts, the upsampling for the center / decoder ones.  The
         # noise tensors are drawn in the reference's order (unet.py:49-74).
         z1, s1 = self.encoder1.forward_lazy(x)
-        p1, z1 = down(z1, s1, noise(self.encoder_dropout1, z1), True)
+        p1, z1 = down(z1, s1, noise(self.encoder_dropout1, z1))
         z2, s2 = self.encoder2.forward_lazy(p1)
-        p2, z2 = down(z2, s2, noise(self.encoder_dropout2, z2), True)
+        p2, z2 = down(z2, s2, noise(self.encoder_dropout2, z2))
         z3, s3 = self.encoder3.forward_lazy(p2)
-        p3, z3 = down(z3, s3, noise(self.encoder_dropout3, z3), True)
+        p3, z3 = down(z3, s3, noise(self.encoder_dropout3, z3))
         z4, s4 = self.encoder4.forward_lazy(p3)
-        p4, z4 = down(z4, s4, noise(self.encoder_dropout4, z4), True)
+        p4, z4 = down(z4, s4, noise(self.encoder_dropout4, z4))
         y, sy = self.center_conv.forward_lazy(p4)
         y, sy = self._up(self.decoder1, y, sy, z4, s4, noise(self.bottleneck_dropout, y))
         y, sy = self._up(self.decoder2, y, sy, z3, s3, noise(self.decoder_dropout1, y))

@@ -68,8 +68,11 @@ class GradSync:
         """Start every replica from rank `src`'s parameters and buffers."""
         if self.world == 1:
             return
-        for t in list(self.model.parameters()) + list(self.model.buffers()):
-            dist.broadcast(t.data, src=src, group=self.group)
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                # through detach() (shares the version counter; `.data` has a fresh one): the in-place
+                # write bumps t._version, which invalidates operand images packed from the old values
+                dist.broadcast(t.detach(), src=src, group=self.group)
 
     def begin_step(self):
         self.ready = [0] * len(self.buckets)

@@ -19,6 +19,7 @@ Single-process only: a gradient exchange inside the captured region is not suppo
 """
 import torch
 
+from .. import functional as F_
 from .optim import CapturedStep, clip_and_step
 
 
@@ -58,7 +59,8 @@ class GraphedTrainStep:
         torch._C._increment_version(self.params)     # the capture must contain the weight re-packing
         torch.cuda.synchronize(images.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # scratch buffers of the captured kernels: allocated in the graph's pool, owned by this object
+        with torch.cuda.graph(self.graph), F_.private_workspaces() as self._workspaces:
             loss, aux = loss_of(model, self.images, self.masks)
             loss.backward()
             norm = self.captured.launch()

@@ -17,14 +17,21 @@ def _attach_counts(logits, targets, cm, status):
 
 
 class diceloss():
-    def __init__(self, class_names, smooth=1e-5):
+    """`global_batch` (not in the reference, which is single-GPU): in a data-parallel run, pool the
+    Dice sums over the batches of ALL ranks before the ratio, as utils/loss_fn.py:79-80 pools over
+    its whole batch (True = the default process group, or pass a group).  The default, False,
+    is the per-rank loss of "N reference replicas with averaged gradients"."""
+
+    def __init__(self, class_names, smooth=1e-5, global_batch=False):
         self.smooth = smooth
         self.class_names = class_names
+        self.global_batch = global_batch
 
     def __call__(self, logits, targets):
         """logits [B, C, H, W] (any float dtype/layout on the GPU), targets [B, H, W] int.
         Returns {class_names[i]: loss_i ..., 'total_loss': sum_i loss_i / C} — 'total_loss' last."""
-        losses, _, cm, status = F_.DiceLossFn.apply(logits, targets, float(self.smooth), False)
+        losses, _, cm, status = F_.DiceLossFn.apply(logits, targets, float(self.smooth), False, F_.LOSS_DICE,
+                                                    self.global_batch or None)
         _attach_counts(logits, targets, cm, status)
         loss_dict = OrderedDict((name, losses[i]) for i, name in enumerate(self.class_names))
         loss_dict["total_loss"] = losses[logits.shape[1] - 1]
@@ -35,12 +42,14 @@ class IOULoss():
     """Drop-in for the reference's utils/loss_fn.py:90-124: same pass, same three pooled sums,
     loss_i = 1 - I/(P + T - I + smooth)."""
 
-    def __init__(self, class_names, smooth=1e-5):
+    def __init__(self, class_names, smooth=1e-5, global_batch=False):
         self.smooth = smooth
         self.class_names = class_names
+        self.global_batch = global_batch
 
     def __call__(self, logits, targets):
-        losses, _, cm, status = F_.DiceLossFn.apply(logits, targets, float(self.smooth), False, F_.LOSS_IOU)
+        losses, _, cm, status = F_.DiceLossFn.apply(logits, targets, float(self.smooth), False, F_.LOSS_IOU,
+                                                    self.global_batch or None)
         _attach_counts(logits, targets, cm, status)
         loss_dict = OrderedDict((name, losses[i]) for i, name in enumerate(self.class_names))
         loss_dict["total_loss"] = losses[logits.shape[1] - 1]

@@ -14,11 +14,17 @@ from .. import functional as F_
 
 
 class Metrics(nn.Module):
-    def __init__(self, class_names: list, smooth=1e-5):
+    def __init__(self, class_names: list, smooth=1e-5, global_batch=False):
+        """`global_batch` (not in the reference, which is single-GPU): in a data-parallel run the
+        per-sample count matrices of all ranks are gathered (B*C*C int64 per rank) before the
+        reference's formulas, so every row — the pooled dice/mIoU rows (metrics.py:95-97,113-115)
+        and the per-sample means — is the one a single process would compute on the global batch.
+        True = the default process group, or pass a group."""
         super().__init__()
         self.class_names = class_names
         self.num_classes = len(class_names)
         self.smooth = smooth
+        self.global_batch = global_batch
 
     # -- GPU part ---------------------------------------------------------------
     def confusion_counts(self, prediction, target):
@@ -30,6 +36,22 @@ class Metrics(nn.Module):
             prediction = prediction[0]
         _, _, cm, status, _, _ = F_.loss_metrics_raw(prediction.detach(), target, False, False, True)
         return cm, status
+
+    def gather_counts(self, cm, status):
+        """Counts of every rank's shard, in rank order (the global batch); identity outside a
+        data-parallel run or with global_batch off."""
+        import torch.distributed as dist
+        if not self.global_batch or not dist.is_initialized():
+            return cm, status
+        pg = None if self.global_batch is True else self.global_batch
+        world = dist.get_world_size(pg)
+        if world == 1:
+            return cm, status
+        packed = torch.cat([cm.reshape(-1), status.to(torch.int64).reshape(-1)])
+        out = torch.empty(world * packed.numel(), dtype=torch.int64, device=cm.device)
+        dist.all_gather_into_tensor(out, packed, group=pg)
+        out = out.view(world, -1)
+        return out[:, :-1].reshape((world * cm.shape[0],) + tuple(cm.shape[1:])), out[:, -1].max().reshape(1)
 
     # -- host part: the reference's formulas on the counts ------------------------
     @staticmethod
@@ -71,7 +93,7 @@ class Metrics(nn.Module):
         return np.nan_to_num(metrics)
 
     def update(self, prediction, target):
-        cm, status = self.confusion_counts(prediction, target)
+        cm, status = self.gather_counts(*self.confusion_counts(prediction, target))
         host = torch.cat([cm.reshape(-1), status.to(torch.int64)]).cpu()     # one D2H copy
         if int(host[-1]) != 0:
             raise RuntimeError("Class values must be smaller than num_classes.")

@@ -10,6 +10,9 @@ Differences that do not change results:
     runs once per epoch on the host, so the step loop has no device->host synchronisation
     (the reference synchronises 7*(n+1) times per batch through .item());
   * per-batch losses are accumulated detached (the reference keeps graph-attached tensors);
+  * a target value outside [0, n_classes) is reported when the epoch's counts are read back (the
+    kernels set a device status word), not on the offending batch as F.one_hot does;
+  * one logits tensor per model call: list / (main, aux) outputs raise NotImplementedError;
   * with a GradSync (data parallel) attached to the model, gradients are averaged across
     ranks before unscale/clip, overlapped with the backward pass;
   * gradient clipping and the AdamW update run as two fused launches on the optimizer's own
@@ -38,6 +41,7 @@ def _finish_metrics(Metric, pending, n_rows):
     total = np.zeros((6, n_rows))
     if not pending:
         return total
+    pending = [Metric.gather_counts(cm, st) for cm, st in pending]      # the global batch in a data-parallel run
     flat = torch.cat([torch.cat([cm.reshape(-1), st.to(torch.int64)]) for cm, st in pending]).cpu()
     off = 0
     for cm, _ in pending:
@@ -47,6 +51,17 @@ def _finish_metrics(Metric, pending, n_rows):
         total += Metric.from_counts(flat[off:off + n].reshape(cm.shape))
         off += n + 1
     return total
+
+
+def _single_output(pred):
+    """The reference's loops also accept models that return a list (U2Net deep supervision) or a
+    (main, aux) pair mixed 0.6/0.4 (train_and_eval.py:75-103, 266-286); the fused loss kernel takes
+    one logits tensor, and none of the models built here returns anything else."""
+    if isinstance(pred, (list, tuple)):
+        raise NotImplementedError("models returning several outputs (deep supervision lists, (main, aux) pairs) "
+                                  "are not supported by the fused loss path: pass a model that returns one "
+                                  "[B, C, H, W] logits tensor")
+    return pred
 
 
 def _device_batches(loader, device):
@@ -101,7 +116,7 @@ def train_one_epoch(model, optimizer, epoch, train_dataloader, device, loss_fn, 
     for images, masks in _device_batches(loader, device):
         optimizer.zero_grad()
         with autocast(device_type="cuda", dtype=torch.bfloat16):
-            pred = model(images)
+            pred = _single_output(model(images))
             masks = masks.to(torch.int64)
             loss_dict = loss_fn(pred, masks)
             losses = list(loss_dict.values())
@@ -143,7 +158,7 @@ def evaluate(model, device, data_loader, loss_fn, Metric, class_names, test: boo
         loader = tqdm(data_loader, desc="  Validating ", leave=False)
         for images, masks in _device_batches(loader, device):
             with autocast(device_type="cuda", dtype=torch.bfloat16):
-                pred_mask = model(images)
+                pred_mask = _single_output(model(images))
                 masks = masks.to(torch.int64)
                 masks = masks.squeeze(1)
                 loss_dict = loss_fn(pred_mask, masks)
