@@ -348,10 +348,12 @@ FUSE_BN_SUMS = True      # producers of `da` that hold z in registers also emit 
 
 def attach_bn_sums(da, sums, z):
     """Tags the gradient tensor `da` (gradient with respect to the activation of the lazy tensor
-    z) with the BatchNorm-backward sums computed alongside it.  The tag only reaches the
-    producing layer's backward if autograd hands the very same tensor object through, i.e. if
-    nothing was accumulated into or derived from it — exactly when the sums are still valid."""
-    da._mis_bn_sums = (sums, z.data_ptr(), z._version, da.data_ptr())
+    z) with the BatchNorm-backward sums computed alongside it.  The tag is honoured only if the
+    very same tensor object arrives at the producing layer's backward with the version counter it
+    had here: when z has several consumers autograd sums their gradients IN PLACE into the first
+    one it received (same object, same pointer, tag still attached — but the counter moved), and
+    the sums of one consumer alone would be wrong."""
+    da._mis_bn_sums = (sums, z.data_ptr(), z._version, da.data_ptr(), da._version)
     return da
 
 
