@@ -79,6 +79,25 @@ int mis_loss_metrics_fwd(const void* logits, int dtype, int64_t stride_b, int64_
                          float* sums, float* ce_map, int64_t* cm, int32_t* status,
                          void* workspace, mis_stream_t stream);
 
+/* mis_loss_metrics_fwd for callers that cannot allocate device memory.  It has   */
+/* no counterpart in the reference; it is for code running under HIP graph        */
+/* capture, tight serving loops and harnesses that forbid hipMalloc: same          */
+/* arguments, same kernels and bit-identical results, minus the workspace — the    */
+/* scratch (per-workgroup partial sums; the count matrices when cm == NULL) is a    */
+/* fixed array inside the library's device image, one copy per GPU, held for the    */
+/* life of the process.  The call allocates and frees nothing.  Problems whose      */
+/* mis_loss_metrics_workspace_bytes(B, C, HW) exceeds                               */
+/* MIS_LOSS_METRICS_STATIC_SCRATCH_BYTES are rejected with MIS_ERR_ARG (for C = 4 */
+/* that allows batches of several thousand images of any size).  All calls on one GPU share */
+/* that GPU's array: calls that may overlap on one GPU (different streams without    */
+/* ordering, several host threads) race on it — serialise them or use the            */
+/* workspace form.  The array's address is looked up on the first call on each GPU   */
+/* (make that call outside graph capture).                                           */
+#define MIS_LOSS_METRICS_STATIC_SCRATCH_BYTES ((size_t)1 << 20)
+int mis_loss_metrics_fwd_static(const void* logits, int dtype, int64_t stride_b, int64_t stride_c, int64_t stride_p,
+                                const int64_t* target, int B, int C, int HW,
+                                float* sums, float* ce_map, int64_t* cm, int32_t* status, mis_stream_t stream);
+
 /* Loss values from the pooled sums — utils/loss_fn.py:81-83 (Dice) and          */
 /* :116-118 (IoU).  losses float32 [C]: for i < C-1, with c = i+1 and            */
 /* U = P_c + T_c:  Dice  losses[i] = 1 - 2 I_c / (U + smooth);                   */

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "mis_last_error": (C.c_char_p, []),
     "mis_loss_metrics_workspace_bytes": (_sz, [_i, _i, _i]),
     "mis_loss_metrics_fwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_loss_metrics_fwd_static": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mis_dice_from_sums": (_i, [_vp, _i, _f, _i, _vp, _vp]),
     "mis_loss_bwd": (_i, [_vp, _i, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "mis_maxpool2x2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -8,6 +8,7 @@
 // written per block and reduced in a fixed order by a second tiny kernel (bitwise
 // reproducible); integer counts are wave-ballot popcounts (C <= 5) or LDS atomics.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -320,6 +321,37 @@ int launch_bwd(const void* logits, int64_t sb, int64_t sc, int64_t sp, const int
   return 0;
 }
 
+// Scratch of the entry point that allocates nothing (mis_loss_metrics_fwd_static): the per-workgroup
+// partial sums and, when the caller wants no counts back, the count matrices.  One copy of this
+// array exists on every GPU the library runs on, at its own address, for the life of the process.
+// In host code the NAME below is only a handle for hipGetSymbolAddress: kernels and memsets get
+// the per-device address kept in static_scratch_ptr.
+constexpr size_t STATIC_SCRATCH_BYTES = MIS_LOSS_METRICS_STATIC_SCRATCH_BYTES;
+constexpr int STATIC_SCRATCH_MAX_DEVICES = 64;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+static std::atomic<void*> static_scratch_ptr[STATIC_SCRATCH_MAX_DEVICES];
+
+// Device address of `scratch` on the CURRENT device, resolved once per device.
+static void* static_scratch(int* status_out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= STATIC_SCRATCH_MAX_DEVICES) {
+    *status_out = MIS_ERR_LAUNCH;
+    mis_set_error("loss_metrics_fwd_static: cannot identify the current device (hipGetDevice gave %d)", dev);
+    return nullptr;
+  }
+  void* p = static_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      *status_out = MIS_ERR_LAUNCH;
+      mis_set_error("loss_metrics_fwd_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return nullptr;
+    }
+    static_scratch_ptr[dev].store(p, std::memory_order_release);    // (two racing threads store the same address)
+  }
+  return p;
+}
+
 #define DISPATCH_C(FN, T, C, ...)                \
   switch (C) {                                   \
     case 2: FN<T, 2>(__VA_ARGS__); break;        \
@@ -376,6 +408,23 @@ int mis_loss_metrics_fwd(const void* logits, int dtype, int64_t sb, int64_t sc, 
     MIS_CHECK_LAUNCH("loss_sums_finalize_kernel");
   }
   return MIS_OK;
+}
+
+int mis_loss_metrics_fwd_static(const void* logits, int dtype, int64_t sb, int64_t sc, int64_t sp,
+                                const int64_t* target, int B, int C, int HW, float* sums, float* ce_map, int64_t* cm,
+                                int32_t* status, mis_stream_t stream) {
+  MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 2 && C <= 16, "loss_metrics_fwd_static: need B,HW >= 1 and 2 <= C <= 16 (C=%d)", C);
+  const size_t need = mis_loss_metrics_workspace_bytes(B, C, HW);
+  MIS_REQUIRE(need <= STATIC_SCRATCH_BYTES,
+              "loss_metrics_fwd_static: B=%d C=%d HW=%d needs %zu bytes of scratch, the built-in buffer holds %zu "
+              "(use mis_loss_metrics_fwd with a caller-provided workspace)", B, C, HW, need, STATIC_SCRATCH_BYTES);
+  int rc = MIS_OK;
+  void* ws = static_scratch(&rc);
+  if (ws == nullptr) return rc;
+  // everything the kernels read from the scratch is written earlier in the same call (partial rows by
+  // every workgroup; the count area is cleared by the memset of mis_loss_metrics_fwd), so what the
+  // previous call left behind is never seen
+  return mis_loss_metrics_fwd(logits, dtype, sb, sc, sp, target, B, C, HW, sums, ce_map, cm, status, ws, stream);
 }
 
 int mis_dice_from_sums(const float* sums, int C, float smooth, int kind, float* losses, mis_stream_t stream) {
