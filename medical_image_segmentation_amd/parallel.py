@@ -60,19 +60,34 @@ class GradSync:
                 self.bucket_of[p] = bi
         self.ready = [0] * len(self.buckets)
         self.handles = [None] * len(self.buckets)
+        self.host = [None] * len(self.buckets)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         model._mis_grad_sync = self
         self.model = model
 
     def broadcast_parameters(self, src=0):
-        """Start every replica from rank `src`'s parameters and buffers."""
+        """Start every replica from rank `src`'s parameters and buffers: one collective per dtype
+        over a flattened copy (not one per tensor).  On RCCL the flat buffer stays on the GPU; other
+        backends (gloo: rehearsal and tests) move it through host memory — gloo's broadcast of
+        device tensors does not complete on this platform, its all-reduce does."""
         if self.world == 1:
             return
+        by_dtype = {}
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            by_dtype.setdefault(t.dtype, []).append(t)
         with torch.no_grad():
-            for t in list(self.model.parameters()) + list(self.model.buffers()):
-                # through detach() (shares the version counter; `.data` has a fresh one): the in-place
-                # write bumps t._version, which invalidates operand images packed from the old values
-                dist.broadcast(t.detach(), src=src, group=self.group)
+            for tensors in by_dtype.values():
+                flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+                if self.avg_in_collective:
+                    dist.broadcast(flat, src=src, group=self.group)
+                else:
+                    host = flat.cpu()
+                    dist.broadcast(host, src=src, group=self.group)
+                    flat = host.to(flat.device)
+                # written through detach() (shares the version counter; `.data` has a fresh one): the
+                # in-place copy bumps t._version, which invalidates operand images packed from old values
+                for t, v in zip(tensors, flat.split([t.numel() for t in tensors])):
+                    t.detach().copy_(v.view_as(t))
 
     def begin_step(self):
         self.ready = [0] * len(self.buckets)
@@ -86,9 +101,14 @@ class GradSync:
             torch.cat(grads, out=flat)            # one batched copy launch for the whole bucket
         else:                                     # gradients accumulated into last step's bucket views
             torch._foreach_copy_(list(flat.split([p.numel() for p in b])), grads)
-        if self.active:
-            self.handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM,
-                                               group=self.group, async_op=True)
+        if self.active and self.avg_in_collective:
+            self.handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        elif self.active:
+            # other backends (gloo: tests and rehearsals) sum a host copy — gloo's asynchronous collectives
+            # on device tensors do not complete on this platform — and have no AVG
+            host = flat.cpu()
+            self.host[bi] = host
+            self.handles[bi] = dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         bi = self.bucket_of[p]
@@ -108,7 +128,7 @@ class GradSync:
                 self.handles[bi].wait()
             flat = self.flat[bi]
             if self.active and not self.avg_in_collective:
-                flat.div_(self.world)             # gloo has no AVG
+                flat.copy_(self.host[bi].div_(self.world))
             if self.active:
                 # the averaged values stay where they are: each p.grad becomes a view of the bucket (no
                 # copy back; the optimizer's pointer table then repeats from step to step)

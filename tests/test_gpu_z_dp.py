@@ -72,3 +72,78 @@ def test_grad_sync_on_rccl_group_of_one():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_matches_reference_replicas(golden, tmp_path):
+    """The HIP UNet on two ranks (two processes on cuda:0, gloo group) over the two shards of the
+    `dp` golden case: per-rank losses and the exchanged (averaged) gradients against the
+    reference's "two replicas, averaged gradients" fixture; then the global-batch mode — Dice sums
+    pooled over both ranks before the ratio (loss_fn.py:79-80 on the whole batch) and count
+    matrices gathered — against the oracle evaluated on the concatenated batch."""
+    import socket
+    import subprocess
+    import sys
+    import numpy as np
+    import make_golden as mg
+    if not torch.cuda.is_available():
+        pytest.fail("GPU suite needs a HIP device")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker.py")
+    env = dict(os.environ, MIS_DP_DEBUG="45")        # a hung rank prints its stacks and exits
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(tmp_path)], env=env)
+             for r in range(2)]
+    try:
+        rcs = [p.wait(timeout=60) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert rcs == [0, 0]
+    r = [torch.load(tmp_path / f"r{k}.pt") for k in range(2)]
+    g = golden("dp")
+    # ---- per-rank loss: N reference replicas with averaged gradients --------------------------
+    got_losses = [r[k]["per_rank"]["losses"][-1] for k in range(2)]
+    np.testing.assert_allclose(got_losses, g["dp.shard_losses"], rtol=1e-5, atol=1e-6)
+    for a, b in zip(r[0]["per_rank"]["grads"], r[1]["per_rank"]["grads"]):
+        assert torch.equal(a, b)                                    # both ranks hold the same average
+    grads = [a.double().numpy() for a in r[0]["per_rank"]["grads"]]
+    norms = np.array([np.sqrt((a ** 2).sum()) for a in grads])
+    scale = g["dp.grad_norms"].max()
+    np.testing.assert_allclose(norms, g["dp.grad_norms"], rtol=2e-3, atol=2e-5 * scale)
+    samples = np.stack([a.reshape(-1)[mg.sample_idx(a.size)] for a in grads])
+    assert np.abs(samples - g["dp.grad_samples"]).max() < 2e-4 * np.abs(g["dp.grad_samples"]).max()
+    # ---- global-batch mode against the oracle on the concatenated batch --------------------------
+    c = dict(B=4, cin=1, ncls=4, hw=32, seed=81)
+    x = torch.from_numpy(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100))
+    t = torch.from_numpy(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+    names = ["a", "b", "c"]
+    sts, logits = [], []
+    for k in range(2):                      # replicas keep rank-local BatchNorm statistics
+        st = orc.make_state(c["cin"], c["ncls"], base=8, seed=c["seed"], dtype=torch.float64)
+        for key in orc.param_keys(st):
+            st[key].requires_grad_(True)
+        sts.append(st)
+        logits.append(orc.unet_forward(x[2 * k:2 * k + 2].double(), st, training=True))
+    ld = orc.dice_loss(torch.cat(logits), t, names)
+    ld["total_loss"].backward()
+    keys = orc.param_keys(sts[0])
+    ref = [sts[0][key].grad + sts[1][key].grad for key in keys]     # gradient of the global loss
+    for k in range(2):
+        np.testing.assert_allclose(r[k]["global"]["losses"], [float(v) for v in ld.values()], rtol=1e-5, atol=1e-6)
+        assert rel(r[k]["global"]["logits"], logits[k].detach()) < 1e-4
+    want = orc.metrics_update(torch.cat([r[0]["global"]["logits"], r[1]["global"]["logits"]]), t, names)
+    for k in range(2):
+        assert np.array_equal(r[k]["global"]["metrics"].numpy(), want)
+    gmax = max(float(a.abs().max()) for a in ref)
+    for key, a, b, want_g in zip(keys, r[0]["global"]["grads"], r[1]["global"]["grads"], ref):
+        assert torch.equal(a, b)
+        if key.endswith(".0.bias") and not key.startswith("out_conv"):
+            continue                        # conv bias under train-mode BatchNorm: analytically zero
+        assert float((a.double() - want_g).abs().max()) < 2e-3 * float(want_g.abs().max()) + 1e-5 * gmax, key
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max())
