@@ -101,8 +101,14 @@ __global__ __launch_bounds__(LM_THREADS) void loss_metrics_kernel(
     float* __restrict__ ce_map,             // [B][HW] or null
     unsigned long long* __restrict__ cm,    // [B][C][C]
     int* __restrict__ status) {
+  // Confusion counts, C <= 5: every thread keeps its C*C bins as 8-bit fields of NR registers
+  // (one shift and NR selects per pixel) and the block adds them up through LDS every <= 252
+  // pixels per thread (before a field can wrap) and at the end.
+  constexpr bool PACKED = (C <= 5);
+  constexpr int NB = C * C, NR = (NB + 3) / 4;
   __shared__ float red[2 * C * (LM_THREADS / 64)];
   __shared__ unsigned int hist[C * C];
+  __shared__ unsigned int pkl[PACKED ? LM_THREADS * NR : 1];
   const int b = blockIdx.y, tid = threadIdx.x;
   const T* lg = logits + (int64_t)b * sb;
   const int64_t* tg = target + (int64_t)b * HW;
@@ -112,53 +118,92 @@ __global__ __launch_bounds__(LM_THREADS) void loss_metrics_kernel(
   float acc[2 * C];
 #pragma unroll
   for (int i = 0; i < 2 * C; i++) acc[i] = 0.f;
-  [[maybe_unused]] unsigned int cnt[(C <= 5) ? C * C : 1];
-  if constexpr (C <= 5) {
+  [[maybe_unused]] unsigned int pk[PACKED ? NR : 1];
 #pragma unroll
-    for (int k = 0; k < C * C; k++) cnt[k] = 0;
-  }
+  for (int k = 0; k < (PACKED ? NR : 1); k++) pk[k] = 0;
+  [[maybe_unused]] auto flush_counts = [&]() {
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      pkl[tid * NR + k] = pk[k];
+      pk[k] = 0;
+    }
+    __syncthreads();
+    // thread -> (bin, one of 8 groups of 32 rows); the 8 partial sums of a bin meet in hist
+    const int k = tid & 31, part = tid >> 5;
+    if (k < NB) {
+      unsigned v = 0;
+      for (int r = part * 32; r < part * 32 + 32; r++) v += (pkl[r * NR + (k >> 2)] >> ((k & 3) * 8)) & 0xffu;
+      if (v) atomicAdd(&hist[k], v);
+    }
+    __syncthreads();
+  };
+  int trips = 0;
   bool bad = false;
 
-  for (int base = blockIdx.x * LM_THREADS; base < HW; base += gridDim.x * LM_THREADS) {
-    const int pix = base + tid;
-    const bool valid = pix < HW;
-    int bin = -1;
-    if (valid) {
-      float x[C], p[C], lse;
-      int amax;
-      load_pixel<T, C, NHWC>(lg, pix, sc, sp, x);
-      const int64_t t64 = tg[pix];
-      softmax_pixel<C>(x, p, lse, amax);
-      const bool t_ok = (t64 >= 0) && (t64 < C);
-      bad |= !t_ok;
-      const int t = t_ok ? (int)t64 : -1;
+  // PPT pixels per thread and trip: all their loads are issued before the first use, so a lane has
+  // PPT*(C*sizeof(T) + 8) bytes in flight instead of one pixel's (the pass is pure streaming and
+  // latency-bound otherwise).  A thread's pixels are LM_THREADS apart: every load instruction of
+  // a wave still covers consecutive pixels.
+  constexpr int PPT = 4;
+  for (int base = blockIdx.x * (LM_THREADS * PPT); base < HW; base += gridDim.x * (LM_THREADS * PPT)) {
+    float x[PPT][C];
+    int64_t t64[PPT];
+    bool valid[PPT];
 #pragma unroll
-      for (int c = 0; c < C; c++) {
-        acc[c] += (t == c) ? p[c] : 0.f;
-        acc[C + c] += p[c];
-      }
-      if (t_ok) bin = t * C + amax;
-      if (ce_map) {
-        float ce = 0.f;
-        if (t > 0) {
-          float xt = 0.f, xs = 0.f;
+    for (int u = 0; u < PPT; u++) {
+      const int pix = base + u * LM_THREADS + tid;
+      valid[u] = pix < HW;
+      const int pl = valid[u] ? pix : 0;                 // (a valid address: sample b has HW >= 1 pixels)
+      load_pixel<T, C, NHWC>(lg, pl, sc, sp, x[u]);
+      t64[u] = tg[pl];
+    }
 #pragma unroll
-          for (int c = 0; c < C; c++) {
-            xt = (t == c) ? x[c] : xt;
-            xs += x[c];
-          }
-          ce = (1.0f - CE_LABEL_SMOOTHING) * (lse - xt) + CE_LABEL_SMOOTHING * (lse - xs * (1.0f / C));
+    for (int u = 0; u < PPT; u++) {
+      const int pix = base + u * LM_THREADS + tid;
+      int bin = -1;
+      if (valid[u]) {
+        float p[C], lse;
+        int amax;
+        softmax_pixel<C>(x[u], p, lse, amax);
+        const bool t_ok = (t64[u] >= 0) && (t64[u] < C);
+        bad |= !t_ok;
+        const int t = t_ok ? (int)t64[u] : -1;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          acc[c] += (t == c) ? p[c] : 0.f;
+          acc[C + c] += p[c];
         }
-        ce_map[(int64_t)b * HW + pix] = ce;
+        if (t_ok) bin = t * C + amax;
+        if (ce_map) {
+          float ce = 0.f;
+          if (t > 0) {
+            float xt = 0.f, xs = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+              xt = (t == c) ? x[u][c] : xt;
+              xs += x[u][c];
+            }
+            ce = (1.0f - CE_LABEL_SMOOTHING) * (lse - xt) + CE_LABEL_SMOOTHING * (lse - xs * (1.0f / C));
+          }
+          ce_map[(int64_t)b * HW + pix] = ce;
+        }
+      }
+      if constexpr (PACKED) {
+        const unsigned inc = bin >= 0 ? 1u << ((bin & 3) * 8) : 0u;
+#pragma unroll
+        for (int k = 0; k < NR; k++) pk[k] += ((bin >> 2) == k) ? inc : 0u;
+      } else {
+        if (bin >= 0) atomicAdd(&hist[bin], 1u);
       }
     }
-    if constexpr (C <= 5) {
-#pragma unroll
-      for (int k = 0; k < C * C; k++) cnt[k] += (unsigned)__popcll(__ballot(bin == k));
-    } else {
-      if (bin >= 0) atomicAdd(&hist[bin], 1u);
+    if constexpr (PACKED) {
+      if (++trips == 63) {          // (uniform over the block: the loop bounds are)
+        flush_counts();
+        trips = 0;
+      }
     }
   }
+  if constexpr (PACKED) flush_counts();
   if (bad) atomicOr(status, 1);
 
   block_sum<2 * C>(acc, red);
@@ -167,13 +212,6 @@ __global__ __launch_bounds__(LM_THREADS) void loss_metrics_kernel(
 #pragma unroll
     for (int i = 0; i < 2 * C; i++) v = (tid == i) ? acc[i] : v;
     partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C) + tid] = v;
-  }
-  if constexpr (C <= 5) {
-    if ((tid & 63) == 0) {
-#pragma unroll
-      for (int k = 0; k < C * C; k++)
-        if (cnt[k]) atomicAdd(&hist[k], cnt[k]);
-    }
   }
   __syncthreads();
   for (int i = tid; i < C * C; i += LM_THREADS)
@@ -260,33 +298,48 @@ __global__ __launch_bounds__(LM_THREADS) void loss_bwd_kernel(
   const T* lg = logits + (int64_t)b * sb;
   T* dl = dlogits + (int64_t)b * sb;
   const int64_t* tg = target + (int64_t)b * HW;
-  for (int pix = blockIdx.x * LM_THREADS + tid; pix < HW; pix += gridDim.x * LM_THREADS) {
-    float x[C], p[C], g[C], lse;
-    int amax;
-    load_pixel<T, C, NHWC>(lg, pix, sc, sp, x);
-    const int t = (int)tg[pix];
-    softmax_pixel<C>(x, p, lse, amax);
-    float dot = 0.f;
+  constexpr int PPT = 4;          // pixels per thread and trip, all loads issued before the first use
+  for (int base = blockIdx.x * (LM_THREADS * PPT); base < HW; base += gridDim.x * (LM_THREADS * PPT)) {
+    float xs[PPT][C], ds[PPT];
+    int ts[PPT];
 #pragma unroll
-    for (int c = 0; c < C; c++) {
-      g[c] = ((t == c) ? A[c] : 0.f) + Bc[c];
-      dot += p[c] * g[c];
+    for (int u = 0; u < PPT; u++) {
+      const int pix = base + u * LM_THREADS + tid;
+      const int pl = pix < HW ? pix : 0;
+      load_pixel<T, C, NHWC>(lg, pl, sc, sp, xs[u]);
+      ts[u] = (int)tg[pl];
+      ds[u] = (dce && ts[u] > 0 && ts[u] < C) ? dce[(int64_t)b * HW + pl] : 0.f;
     }
-    const float d = (dce && t > 0 && t < C) ? dce[(int64_t)b * HW + pix] : 0.f;
 #pragma unroll
-    for (int c = 0; c < C; c++) {
-      float v = p[c] * (g[c] - dot);
-      const float onehot = (t == c) ? 1.f : 0.f;
-      v += d * ((1.0f - CE_LABEL_SMOOTHING) * (p[c] - onehot) + CE_LABEL_SMOOTHING * (p[c] - 1.0f / C));
-      g[c] = v;
+    for (int u = 0; u < PPT; u++) {
+      const int pix = base + u * LM_THREADS + tid;
+      if (pix >= HW) continue;
+      float p[C], g[C], lse;
+      int amax;
+      const int t = ts[u];
+      softmax_pixel<C>(xs[u], p, lse, amax);
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        g[c] = ((t == c) ? A[c] : 0.f) + Bc[c];
+        dot += p[c] * g[c];
+      }
+      const float d = ds[u];
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        float v = p[c] * (g[c] - dot);
+        const float onehot = (t == c) ? 1.f : 0.f;
+        v += d * ((1.0f - CE_LABEL_SMOOTHING) * (p[c] - onehot) + CE_LABEL_SMOOTHING * (p[c] - 1.0f / C));
+        g[c] = v;
+      }
+      store_pixel<T, C, NHWC>(dl, pix, sc, sp, g);
     }
-    store_pixel<T, C, NHWC>(dl, pix, sc, sp, g);
   }
 }
 
 inline int lm_blocks_per_sample(int B, int HW) {
-  int want = cdiv(HW, LM_THREADS * 4);              // >= 4 pixels per thread where possible
-  int cap = cdiv(2048, B);                           // ~2048 blocks in flight over the chip
+  int want = cdiv(HW, LM_THREADS * 16);             // >= 16 pixels (four trips of 4) per thread where possible
+  int cap = cdiv(1024, B);                           // ~1024 blocks (four per CU) over the chip
   int n = want < cap ? want : cap;
   return n < 1 ? 1 : n;
 }
@@ -305,11 +358,18 @@ int launch_fwd(const void* logits, int64_t sb, int64_t sc, int64_t sp, const int
   return 0;
 }
 
+inline int lm_bwd_blocks_per_sample(int B, int HW) {
+  int want = cdiv(HW, LM_THREADS * 4);              // one trip of 4 pixels per thread
+  int cap = cdiv(2048, B);
+  int n = want < cap ? want : cap;
+  return n < 1 ? 1 : n;
+}
+
 template <typename T, int C>
 int launch_bwd(const void* logits, int64_t sb, int64_t sc, int64_t sp, const int64_t* target, int B, int HW,
                const float* sums, const float* w, float smooth, int kind, const float* dce, void* dlogits,
                hipStream_t st) {
-  dim3 grid(lm_blocks_per_sample(B, HW), B);
+  dim3 grid(lm_bwd_blocks_per_sample(B, HW), B);
   const bool nhwc = (sc == 1 && sp == C && sb % C == 0 && ((uintptr_t)logits % 16) == 0 &&
                      ((uintptr_t)dlogits % 16) == 0);
   if (nhwc)
