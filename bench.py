@@ -64,30 +64,59 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, threads):
-    """The oracle's train_step (reference semantics, fp32, torch CPU) on a bounded sample:
-    2 images of the same 512x512 workload per step, 1 warm-up + 2 timed steps."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(threads):
+    """The reference's CPU train step as restated by oracle/ (kind "port": the reference itself
+    cannot travel to this box), on BASELINE.json configs[0]: UNet(in=1, 4 classes, base 32), fp32,
+    batch 4, 256x256, torch.randn images / randint masks from a seed-0 generator, AdamW(8e-4,
+    wd 1e-4, betas (0.95, 0.999)), Dice loss, clip_grad_norm_(1.0).  The metrics phase runs the
+    reference's own pass structure (7 argmax + 14 one-hot passes per call), so the step costs what
+    the reference's step costs.  3 warm-up + 20 timed steps on all cores this process may use
+    (capped at 64), and 3 + 10 on 8 threads for comparison with the figure measured where the
+    reference itself runs; `value` is the faster of the two."""
     from oracle import unet_oracle as orc
-    if threads <= 0:
-        threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    B = 2
-    g = torch.Generator().manual_seed(0)
-    st = orc.make_state(1, 4, base=32, seed=1)
-    ts = orc.TrainState(st)
-    x = torch.randn(B, 1, size, size, generator=g)
-    t = torch.randint(0, 4, (B, size, size), generator=g)
-    timers = {}
-    orc.train_step(ts, x, t, ["a", "b", "c"])
-    n = 2
-    t0 = time.perf_counter()
-    for _ in range(n):
-        orc.train_step(ts, x, t, ["a", "b", "c"], timers=timers)
-    dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n} timed steps (after 1 warm-up) of batch {B} at {size}x{size}, fp32, torch CPU "
-                      f"restatement of the reference step",
-            "phase_ms_per_step": {k: round(1e3 * v / n, 1) for k, v in timers.items()}}
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    limit = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if limit > 0:
+        avail = min(avail, limit)
+    avail = max(1, min(avail, 64))
+    counts = [threads] if threads > 0 else sorted({avail, min(8, avail)}, reverse=True)
+    B, S, names = 4, 256, ["a", "b", "c"]
+    runs = []
+    orc.ATEN_FUSED = True          # BatchNorm / upsampling through the ATen calls the reference makes
+    for n_thr in counts:
+        torch.set_num_threads(n_thr)
+        g = torch.Generator().manual_seed(0)
+        ts = orc.TrainState(orc.make_state(1, 4, base=32, seed=1))
+        x = torch.randn(B, 1, S, S, generator=g)
+        t = torch.randint(0, 4, (B, S, S), generator=g)
+        for _ in range(3):
+            orc.train_step(ts, x, t, names, per_call_metrics=True)
+        timers, n = {}, (20 if n_thr == counts[0] else 10)     # (the comparison run is shorter)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            orc.train_step(ts, x, t, names, timers=timers, per_call_metrics=True)
+        dt = time.perf_counter() - t0
+        runs.append({"threads": n_thr, "timed_steps": n, "images_per_s": round(B * n / dt, 3), "ms_per_step": round(1e3 * dt / n, 1),
+                     "phase_ms_per_step": {k: round(1e3 * v / n, 1) for k, v in timers.items()}})
+    best = max(runs, key=lambda r: r["images_per_s"])
+    return {"value": best["images_per_s"], "unit": "images/s", "cores": best["threads"], "kind": "port",
+            "cpu": cpu_model(),
+            "sample": "20 timed steps (after 3 warm-up) of batch 4 at 256x256, fp32 (BASELINE configs[0]): torch-CPU "
+                      "restatement of the reference step, metrics computed pass by pass as the reference does",
+            "runs": runs}
 
 
 def pmc_traffic(roof, B, S, dtype):
@@ -302,7 +331,7 @@ def main():
             out["roofline"] = roof["dominant"]
             out["kernels"] = roof["kernels"]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(S, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_threads)
         if stdout_fd is not None:
             sys.stdout.flush()
             os.dup2(stdout_fd, 1)

@@ -35,6 +35,14 @@ BN_MOMENTUM = 0.1      # nn.BatchNorm2d default
 # ----------------------------------------------------------------------------
 # model pieces
 # ----------------------------------------------------------------------------
+# The restatements below spell BatchNorm and the bilinear upsampling out step by step (they are
+# what the parity tests read).  The reference itself calls ATen's fused kernels for both
+# (nn.BatchNorm2d -> F.batch_norm, nn.Upsample -> F.interpolate); with ATEN_FUSED set the same
+# calls are used here — same results to rounding (tests/test_oracle_golden.py), the reference's
+# own CPU cost.  Only the CPU-baseline timing sets it.
+ATEN_FUSED = False
+
+
 def conv3x3(x, w, b):
     """nn.Conv2d(kernel_size=3, padding=1) — modules.py:87,92."""
     return F.conv2d(x, w, b, stride=1, padding=1)
@@ -69,6 +77,10 @@ def conv_bn_relu(x, state, prefix, training=True, update_stats=True):
     'encoder1.cbr1'; keys follow the reference state_dict ('.0.weight', '.1.running_mean', ...)."""
     z = conv3x3(x, state[prefix + ".0.weight"], state[prefix + ".0.bias"])
     g, b = state[prefix + ".1.weight"], state[prefix + ".1.bias"]
+    if ATEN_FUSED and training and update_stats:
+        state[prefix + ".1.num_batches_tracked"] += 1
+        return torch.relu(F.batch_norm(z, state[prefix + ".1.running_mean"], state[prefix + ".1.running_var"], g, b,
+                                       True, BN_MOMENTUM, BN_EPS))
     if training:
         y, mean, var = batchnorm_train(z, g, b)
         if update_stats:
@@ -95,6 +107,8 @@ def upsample2x_bilinear(x):
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True), restated:
     src = dst*(in-1)/(out-1); i0=floor(src); i1=min(i0+1,in-1); l1=src-i0; l0=1-l1;
     out = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)."""
+    if ATEN_FUSED:
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
     B, C, H, W = x.shape
     Ho, Wo = 2 * H, 2 * W
 
@@ -441,6 +455,53 @@ def metrics_update(logits, target, class_names, smooth=1e-5):
     return metrics_from_counts(confusion_counts(logits, target), len(class_names), smooth)
 
 
+def metrics_update_per_call(logits, target, class_names, smooth=1e-5):
+    """The same (6, n+1) matrix computed the way Metrics.update (metrics.py:137-152) spends its
+    time: every metric function starts over from the logits — recall, precision (each once more
+    inside f1_score, metrics.py:76-77) and accuracy take argmax -> one-hot of prediction and
+    target (9 wide for recall/precision, n+1 otherwise) -> the four torch.where(...).sum((-2,-1))
+    passes of compute_confusion_matrix (metrics.py:31-34); dice and mIoU take softmax -> argmax
+    -> one-hots -> pooled products (metrics.py:87-97,106-115).  7 argmax and 14 one-hot tensors
+    per call.  Used where the CPU baseline must cost what the reference costs; values equal
+    metrics_update's (tests/test_oracle_golden.py)."""
+    n = len(class_names)
+    target = target.to(torch.int64)
+
+    def onehots(K, softmax_first):
+        x = torch.softmax(logits, dim=1) if softmax_first else logits
+        pred = F.one_hot(torch.argmax(x, dim=1).to(torch.int64), num_classes=K).permute(0, 3, 1, 2).float()
+        return pred, F.one_hot(target, num_classes=K).permute(0, 3, 1, 2).float()
+
+    def four_counts(pred, tgt):
+        hit = lambda a, b: torch.where((pred == a) & (tgt == b), 1, 0).sum(dim=(-2, -1))
+        return hit(1, 1), hit(0, 1), hit(1, 0), hit(0, 0)          # TP, FN, FP, TN
+
+    def row(v):                                                      # n per-class values + mean of [1:]
+        return [v[i + 1].item() for i in range(n)] + [v[1:].mean().item()]
+
+    def recall():
+        tp, fn, _, _ = four_counts(*onehots(9, False))
+        return row((tp / (tp + fn + smooth)).mean(dim=0))
+
+    def precision():
+        tp, _, fp, _ = four_counts(*onehots(9, False))
+        return row((tp / (tp + fp + smooth)).mean(dim=0))
+
+    def pooled(iou):
+        pred, tgt = onehots(n + 1, True)
+        inter = (pred * tgt).sum(dim=(0, -2, -1))
+        union = pred.sum(dim=(0, -2, -1)) + tgt.sum(dim=(0, -2, -1))
+        return row(inter / (union - inter + smooth) if iou else (2 * inter) / (union + smooth))
+
+    recalls, precisions, dices = recall(), precision(), pooled(False)
+    r2, p2 = recall(), precision()                                   # f1_score recomputes both
+    f1s = [2 * (r2[i] * p2[i]) / (r2[i] + p2[i] + smooth) for i in range(n + 1)]
+    mious = pooled(True)
+    tp, fn, fp, tn = four_counts(*onehots(n + 1, False))
+    accs = row(((tp + tn) / (tp + tn + fn + fp + smooth)).mean(dim=0))
+    return np.nan_to_num(np.stack([recalls, precisions, dices, f1s, mious, accs], axis=0))
+
+
 # ----------------------------------------------------------------------------
 # one training step (the CPU baseline's unit of work)
 # ----------------------------------------------------------------------------
@@ -482,11 +543,12 @@ class TrainState:
         self.step = 0
 
 
-def train_step(ts, images, masks, class_names, lr=8e-4, timers=None):
+def train_step(ts, images, masks, class_names, lr=8e-4, timers=None, per_call_metrics=False):
     """One batch of train_one_epoch (train_and_eval.py:63-121) on the fp32 CPU path
     (autocast and GradScaler disable themselves without CUDA): forward, Dice loss,
     metrics, backward, clip_grad_norm_(1.0), AdamW.  Returns (loss dict values as
-    floats, metrics matrix, logits)."""
+    floats, metrics matrix, logits).  per_call_metrics: compute the metrics with the
+    reference's own pass structure (its cost), not from one count matrix."""
     import time
     tick = time.perf_counter
     st = ts.state
@@ -498,7 +560,8 @@ def train_step(ts, images, masks, class_names, lr=8e-4, timers=None):
     t1 = tick()
     ld = dice_loss(logits, masks, class_names)
     t2 = tick()
-    met = metrics_update(logits, masks, class_names)
+    met = (metrics_update_per_call(logits.detach(), masks, class_names) if per_call_metrics
+           else metrics_update(logits, masks, class_names))
     t3 = tick()
     ld["total_loss"].backward()
     t4 = tick()

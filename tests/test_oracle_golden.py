@@ -137,6 +137,43 @@ def test_metrics_bit_exact(golden, name):
     assert np.array_equal(m, g[f"{name}.matrix"]), (m - g[f"{name}.matrix"])
 
 
+@pytest.mark.parametrize("name", list(mg.metric_cases()))
+def test_metrics_per_call_restatement_equals_reference(golden, name):
+    """The pass-by-pass restatement (the one the CPU baseline times) gives the reference's matrix
+    bit for bit, like the count-matrix form."""
+    g = golden("metrics")
+    c = mg.metric_cases()[name]
+    x, t = mg.metric_inputs(c)
+    m = orc.metrics_update_per_call(T(x), T(t), [f"c{i}" for i in range(1, c["n"] + 1)])
+    assert np.array_equal(m, g[f"{name}.matrix"])
+
+
+def test_aten_fused_timing_mode_equals_restatement():
+    """The oracle's timing mode (ATen's fused batch_norm / interpolate, as the reference calls
+    them) computes the same training step as the step-by-step restatement."""
+    names = ["a", "b", "c"]
+    x = T(dg.hash_normalish((2, 1, 32, 32), 9001))
+    t = T(dg.blob_mask(2, 32, 32, 4, 9002))
+    out = []
+    for fused in (False, True):
+        orc.ATEN_FUSED = fused
+        try:
+            ts = orc.TrainState(orc.make_state(1, 4, base=8, seed=33))
+            for _ in range(2):
+                losses, met, logits = orc.train_step(ts, x, t, names)
+        finally:
+            orc.ATEN_FUSED = False
+        # (conv biases under train-mode BatchNorm have an analytically zero gradient; AdamW turns its
+        # round-off into +-lr steps, which also reach the running means: both are left out)
+        out.append((losses, met, logits, [ts.state[k].detach().clone() for k in ts.state
+                                          if k.endswith((".0.weight", ".1.weight", ".1.bias", ".running_var"))
+                                          or k.startswith("out_conv")]))
+    close(out[0][0], out[1][0], 1e-5, 1e-6)
+    assert float((out[0][2] - out[1][2]).abs().max()) < 1e-4 * float(out[0][2].abs().max())
+    for a, b in zip(out[0][3], out[1][3]):
+        assert float((a.double() - b.double()).abs().max()) < 2e-3 * float(a.double().abs().max()) + 1e-5
+
+
 def test_train_steps(golden):
     g = golden("train")
     c = mg.train_case()
