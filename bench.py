@@ -330,6 +330,7 @@ def main():
         if roof is not None:
             out["roofline"] = roof["dominant"]
             out["kernels"] = roof["kernels"]
+            out["conv_layers"] = roof["conv_layers"]      # every conv shape against its own roof (HBM or matrix cores)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_threads)
         if stdout_fd is not None:

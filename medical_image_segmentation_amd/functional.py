@@ -106,10 +106,10 @@ PROFILE = None        # None = off; a dict = collect {family: [(start_event, end
 
 
 class _prof:
-    __slots__ = ("name", "flops", "nbytes", "e0")
+    __slots__ = ("name", "flops", "nbytes", "tag", "e0")
 
-    def __init__(self, name, flops, nbytes):
-        self.name, self.flops, self.nbytes = name, flops, nbytes
+    def __init__(self, name, flops, nbytes, tag=None):
+        self.name, self.flops, self.nbytes, self.tag = name, flops, nbytes, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -121,24 +121,37 @@ class _prof:
         if PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.setdefault(self.name, []).append((self.e0, e1, self.flops, self.nbytes))
+            PROFILE.setdefault(self.name, []).append((self.e0, e1, self.flops, self.nbytes, self.tag))
         return False
 
 
 def profile_summary(peak_hbm_gbs, peak_tflops, steps=1):
     """Per kernel family: time per step, algorithmic GB/s and TFLOP/s, and the roofline
     object of the family with the largest time share."""
-    fams = {}
+    fams, layers = {}, {}
     for name, recs in (PROFILE or {}).items():
-        ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+        times = [a.elapsed_time(b) for a, b, _, _, _ in recs]
+        ms = sum(times)
         fl = sum(r[2] for r in recs)
         by = sum(r[3] for r in recs)
+        for t, r in zip(times, recs):
+            if r[4] is not None:            # per-shape lines of the conv families
+                e = layers.setdefault(f"{name} {r[4]}", [0.0, 0, 0, 0])
+                e[0] += t; e[1] += 1; e[2] += r[2]; e[3] += r[3]
         fams[name] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": len(recs) // steps,
                       "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                       "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 and fl else None,
                       "alg_bytes_per_step": by // steps, "alg_flops_per_step": fl // steps}
+    per_layer = {}
+    for key, (t, n, fl, by) in layers.items():
+        # each shape against ITS roof: the larger of bytes / HBM peak and flops / matrix-core peak
+        t_hbm, t_mfma = by / (peak_hbm_gbs * 1e9), fl / (peak_tflops * 1e12)
+        per_layer[key] = {"us": round(1e3 * t / n, 1), "launches_per_step": n // steps,
+                          "GBps": round(by / (t * 1e-3) / 1e9, 1), "TFLOPs": round(fl / (t * 1e-3) / 1e12, 1),
+                          "bound": "mfma" if t_mfma > t_hbm else "hbm",
+                          "roofline_frac": round(max(t_hbm, t_mfma) / (t * 1e-3), 3)}
     if not fams:
-        return {"dominant": None, "kernels": {}}
+        return {"dominant": None, "kernels": {}, "conv_layers": {}}
     dom = max(fams, key=lambda k: fams[k]["ms_per_step"])
     d = fams[dom]
     t_hbm = d["alg_bytes_per_step"] / (peak_hbm_gbs * 1e9)
@@ -153,7 +166,7 @@ def profile_summary(peak_hbm_gbs, peak_tflops, steps=1):
                  "launches_per_step": d["launches_per_step"],
                  "algorithmic_bytes_per_launch": d["alg_bytes_per_step"] // max(d["launches_per_step"], 1),
                  "traffic": None})
-    return {"dominant": roof, "kernels": fams}
+    return {"dominant": roof, "kernels": fams, "conv_layers": per_layer}
 
 
 # ---------------------------------------------------------------------------
@@ -283,7 +296,8 @@ def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None, x2=None, x2_ss=N
     else:
         stats = torch.empty((2, Cout), dtype=torch.float32, device=x.device) if want_stats else None
     es = x.element_size()
-    with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, (B * H * W * (Cin + Cout) + 9 * Cin * Cout) * es):
+    with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, (B * H * W * (Cin + Cout) + 9 * Cin * Cout) * es,
+               f"{Cin}->{Cout}@{H}x{W}"):
         if x2 is None:
             call("mis_conv3x3_fwd", x.data_ptr(), _p(x_ss), w_packed.data_ptr(), _p(bias),
                  _dt(x), B, H, W, Cin, Cout, z.data_ptr(), _p(stats), ws.data_ptr(), _stream())
@@ -301,7 +315,7 @@ def conv3x3_split_raw(x, w_packed, Ca, Cb):
     ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Ca + Cb), x.device)
     es = x.element_size()
     with _prof("conv3x3_fwd", 18 * B * H * W * Cin * (Ca + Cb),
-               (B * H * W * (Cin + Ca + Cb) + 9 * Cin * (Ca + Cb)) * es):
+               (B * H * W * (Cin + Ca + Cb) + 9 * Cin * (Ca + Cb)) * es, f"{Cin}->{Ca}+{Cb}@{H}x{W}"):
         call("mis_conv3x3_split_fwd", x.data_ptr(), None, w_packed.data_ptr(), None, _dt(x), B, H, W, Cin, Ca, Cb,
              za.data_ptr(), zb.data_ptr(), ws.data_ptr(), _stream())
     return za, zb
@@ -321,7 +335,7 @@ def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None, bias_rows=None):
         rows, n_rows = bias_rows
         dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
     with _prof("conv3x3_wgrad", 18 * B * H * W * Cin * Cout,
-               B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout):
+               B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout, f"{Cin}->{Cout}@{H}x{W}"):
         if x2 is None:
             call("mis_conv3x3_wgrad", x.data_ptr(), _p(x_ss), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout,
                  dw.data_ptr(), _p(rows), n_rows, _p(dbias), ws.data_ptr(), _stream())
@@ -390,7 +404,8 @@ def _dgrad_with_bn_sums(dz, wd, x, x_ss):
     dx = torch.empty_like(x)
     sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
     ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Cout), x.device)
-    with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, B * H * W * (Cin + 2 * Cout) * x.element_size()):
+    with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, B * H * W * (Cin + 2 * Cout) * x.element_size(),
+               f"{Cin}->{Cout}@{H}x{W} +bn sums"):
         call("mis_conv3x3_dgrad_bn_sums", dz.data_ptr(), wd.data_ptr(), _dt(x), B, H, W, Cin, Cout, dx.data_ptr(),
              x.data_ptr(), x_ss.data_ptr(), sums.data_ptr(), ws.data_ptr(), _stream())
     return attach_bn_sums(dx, sums, x)

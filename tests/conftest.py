@@ -45,3 +45,19 @@ def _isolated_test_state():
     finally:
         for n, v in saved.items():
             setattr(F_, n, v)
+
+
+@pytest.fixture
+def report(request):
+    """report(label, value): prints a measured error (shown with -rA / on failure) and appends it
+    to gpurun_out/parity_report.txt, so the margins behind the asserted bounds can be read."""
+    def _report(label, value):
+        line = f"{request.node.name}: {label} = {value:.3e}"
+        print(line)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "parity_report.txt"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+    return _report
