@@ -232,6 +232,19 @@ int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int 
                       int Cin, int Cout, float* dw, const float* bias_rows, int n_bias_rows, float* dbias,
                       void* workspace, mis_stream_t stream);
 
+/* The same conv with DILATED taps: nn.Conv2d(kernel_size=3, padding=d, dilation=d), d = 2, 3 */
+/* — ResDConv.cbr2 / cbr3, model/utils/modules.py:440-445 (d = 1 is the plain conv).  The data  */
+/* gradient of a dilated conv is mis_conv3x3_dilated_fwd on the transposed weight image with    */
+/* the same d.  Matrix-core kernels only (no vector-ALU fallback): *_supported tells.           */
+int mis_conv3x3_dilated_supported(int dtype, int B, int H, int W, int Cin, int Cout, int dilation);
+int mis_conv3x3_dilated_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout, int dilation);
+int mis_conv3x3_dilated_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype,
+                            int B, int H, int W, int Cin, int Cout, int dilation, void* z, float* stats,
+                            void* workspace, mis_stream_t stream);
+int mis_conv3x3_dilated_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W,
+                              int Cin, int Cout, int dilation, float* dw, const float* bias_rows, int n_bias_rows,
+                              float* dbias, void* workspace, mis_stream_t stream);
+
 /* The decoder's `torch.cat([up(x), skip], dim=1)` followed by a 3x3 conv         */
 /* (model/unet.py:66-68, 71-73, 76-78, 80-82) without materialising the          */
 /* concatenation: the conv reads its input channels [0,Ca) from xa and [Ca,Ca+Cb) */
@@ -292,6 +305,15 @@ int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_p
 int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, int C,
                        const float* mean_rstd, const float* gamma, const float* beta, const float* sums,
                        void* dz, float* dbias, void* workspace, mis_stream_t stream);
+/* The same two passes for a BatchNorm2d that is NOT followed by a ReLU of its own  */
+/* (ResDConv's `c1` and `cbr3`, model/utils/modules.py:432-433,444-445): dy is the    */
+/* gradient of the BatchNorm output as it is, no mask.                               */
+int mis_bn_bwd_reduce(const void* z, const void* dy, int dtype, int64_t n_pix, int C,
+                      const float* mean_rstd, const float* gamma, const float* beta,
+                      float* sums, void* workspace, mis_stream_t stream);
+int mis_bn_bwd_dz(const void* z, const void* dy, int dtype, int64_t n_pix, int C,
+                  const float* mean_rstd, const float* gamma, const float* beta, const float* sums,
+                  void* dz, float* dbias, void* workspace, mis_stream_t stream);
 /* Per-channel sum over pixels of a channels-last tensor (conv bias gradient).   */
 size_t mis_channel_sum_workspace_bytes(int64_t n_pix, int C);
 int mis_channel_sum(const void* x, int dtype, int64_t n_pix, int C, float* out, void* workspace,
@@ -353,6 +375,40 @@ int mis_dwconv_compose_fwd(const float* P, const float* D, const float* bd, cons
                            float* W, float* b, mis_stream_t stream);
 int mis_dwconv_compose_bwd(const float* P, const float* D, const float* bd, const float* dW, const float* db, int Cout,
                            int Cin, float* dP, float* dD, float* dbd, mis_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* RDAM_UNet (model/rdam_unet.py:7-115): what is not a convolution.              */
+/*                                                                               */
+/* ResDConv tail, model/utils/modules.py:447-453: out = relu(bn3(z3) + bn1(z1))   */
+/* from the two conv outputs and their [2][C] (scale, shift): `x = x + re;        */
+/* return self.relu(x)` and the two BatchNorm applications in one pass.           */
+int mis_add_bn_relu_fwd(const void* za, const float* za_affine, const void* zb, const float* zb_affine, int dtype,
+                        int64_t n_pix, int C, void* out, mis_stream_t stream);
+/* Its backward's first step: g = dout where out > 0, else 0 (the gradient of both */
+/* BatchNorm outputs).                                                             */
+int mis_relu_mask_bwd(const void* out, const void* dout, int dtype, int64_t n_pix, int C, void* g,
+                      mis_stream_t stream);
+/* MDAM, model/utils/attention.py:171-190: out = x * sigmoid(w[b][c]) with          */
+/* w = softmax(avgpool(GroupNorm(..))) + fc(avgpool(conv3x3(x))).  The first term is  */
+/* the GroupNorm bias whatever x is (one channel per group: the average of a          */
+/* normalised map is its bias), the second needs only the nine zero-padded window     */
+/* sums of x per (sample, channel):                                                   */
+/*   S float32 [B][C][9], S[b][c][ky*3+kx] = sum of x[b][.][.][c] over the pixels     */
+/*   that tap (ky, kx) of a 3x3 / padding-1 conv reads (attention.py:184-185:         */
+/*   avgpool(conv3x3(x))[co] = bias[co] + sum_ci,tap W[co][ci][tap]*S[ci][tap]/(H*W)).  */
+/* mis_mdam_window_sums_bwd: dx[b][p][c] = sum of dS[b][c][tap] over the taps whose     */
+/* window contains p.  mis_channel_scale: out = x * s[b][c] (attention.py:189);          */
+/* mis_channel_dot: out[b][c] = sum_p x*d (its gradient with respect to s).              */
+/* Workspace of both reductions: mis_mdam_workspace_bytes.  C a multiple of the          */
+/* 16-byte channel vector, C <= 2048 (bfloat16) / 1024 (float32).                        */
+size_t mis_mdam_workspace_bytes(int B, int C);
+int mis_mdam_window_sums(const void* x, int dtype, int B, int H, int W, int C, float* S, void* workspace,
+                         mis_stream_t stream);
+int mis_mdam_window_sums_bwd(const float* dS, int dtype, int B, int H, int W, int C, void* dx, mis_stream_t stream);
+int mis_channel_scale(const void* x, const float* s, int dtype, int B, int64_t HW, int C, void* out,
+                      mis_stream_t stream);
+int mis_channel_dot(const void* x, const void* d, int dtype, int B, int64_t HW, int C, float* out, void* workspace,
+                    mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Sliding-window prediction — utils/slide_predict.py:60-117.                    */

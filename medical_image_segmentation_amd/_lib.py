@@ -47,6 +47,10 @@ PROTOTYPES = {
     "mis_conv3x3_dgrad_bn_sums": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mis_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "mis_conv3x3_dilated_supported": (_i, [_i] * 7),
+    "mis_conv3x3_dilated_stats_rows": (_i, [_i] * 7),
+    "mis_conv3x3_dilated_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mis_conv3x3_dilated_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "mis_clip_adamw_workspace_bytes": (_sz, [_i]),
     "mis_grad_sqsum": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mis_clip_adamw_step": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _d, _d, _d, _d, _d, _i64, _i, _vp, _vp]),
@@ -63,6 +67,15 @@ PROTOTYPES = {
     "mis_bn_relu_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_dz_rows": (_i, [_i, _i64, _i]),
     "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_add_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
+    "mis_relu_mask_bwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp]),
+    "mis_mdam_workspace_bytes": (_sz, [_i, _i]),
+    "mis_mdam_window_sums": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_mdam_window_sums_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_channel_scale": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp]),
+    "mis_channel_dot": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp]),
     "mis_channel_sum_workspace_bytes": (_sz, [_i64, _i]),
     "mis_channel_sum": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp]),
     "mis_conv1x1_fwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),

@@ -159,6 +159,7 @@ struct BnBwdReduce {
   const float* gamma;
   const float* beta;
   int C;
+  int relu;                                    // 0: BatchNorm alone (no ReLU mask on the gradient)
   float mean[V], rstd[V], gam[V], bet[V];      // this thread's channel constants
   __device__ __forceinline__ void prepare(int c0) {
 #pragma unroll
@@ -177,7 +178,7 @@ struct BnBwdReduce {
     for (int k = 0; k < V; k++) {
       const float xh = (zv[k] - mean[k]) * rstd[k];
       const float y = xh * gam[k] + bet[k];
-      const float dy = (y > 0.f) ? gv[k] : 0.f;
+      const float dy = (!relu || y > 0.f) ? gv[k] : 0.f;
       acc[0][k] += dy;
       acc[1][k] += dy * xh;
     }
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
                                                                     const float* __restrict__ sums,
-                                                                    float* __restrict__ dz_partials) {
+                                                                    float* __restrict__ dz_partials, int relu) {
   extern __shared__ float prm[];   // scratch for the optional bias partial: [256][V]
   const int CV = C / V;
   const int64_t i0 = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
     for (int k = 0; k < V; k++) {
       const float xh = (zv[k] - mean[k]) * rstd[k];
       const float y = xh * gam[k] + bet[k];
-      const float dy = (y > 0.f) ? gv[k] : 0.f;
+      const float dy = (!relu || y > 0.f) ? gv[k] : 0.f;
       o[k] = gam[k] * rstd[k] * (dy - m1[k] - xh * m2[k]);
       bsum[k] += to_f32(from_f32<T>(o[k]));
     }
@@ -273,13 +274,13 @@ int apply_t(const void* z, void* a, int64_t n_pix, int C, const float* ss, hipSt
 
 template <typename T>
 int bwd_reduce_t(const void* z, const void* da, int64_t n_pix, int C, const float* mean_rstd, const float* gamma,
-                 const float* beta, float* sums, void* ws, hipStream_t st) {
+                 const float* beta, float* sums, void* ws, hipStream_t st, int relu) {
   constexpr int N = VecOf<T>::N;
   if (pick_vec<T>(C, z, da) == N) {
-    BnBwdReduce<T, N> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C, {}, {}, {}, {}};
+    BnBwdReduce<T, N> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C, relu, {}, {}, {}, {}};
     launch_channel_reduce<N>(f, n_pix, C, (float*)ws, sums, st);
   } else {
-    BnBwdReduce<T, 1> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C, {}, {}, {}, {}};
+    BnBwdReduce<T, 1> f{(const T*)z, (const T*)da, mean_rstd, gamma, beta, C, relu, {}, {}, {}, {}};
     launch_channel_reduce<1>(f, n_pix, C, (float*)ws, sums, st);
   }
   return 0;
@@ -293,7 +294,8 @@ static inline int bwd_dz_grid(int64_t n, int C, int V) {
 
 template <typename T>
 int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, const float* mean_rstd,
-             const float* gamma, const float* beta, const float* sums, float* dbias, void* ws, hipStream_t st) {
+             const float* gamma, const float* beta, const float* sums, float* dbias, void* ws, hipStream_t st,
+             int relu) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = n_pix * C;
   const size_t lds = (size_t)EW_THREADS * N * sizeof(float);
@@ -304,10 +306,10 @@ int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, cons
   float* partials = dbias ? (float*)ws : nullptr;
   if (vec)
     bn_relu_bwd_dz_kernel<T, N><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n,
-                                                                 mean_rstd, gamma, beta, sums, partials);
+                                                                 mean_rstd, gamma, beta, sums, partials, relu);
   else
     bn_relu_bwd_dz_kernel<T, 1><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n, C, inv_n,
-                                                                 mean_rstd, gamma, beta, sums, partials);
+                                                                 mean_rstd, gamma, beta, sums, partials, relu);
   // dbias == workspace: the caller takes the partial rows [grid][C] as they are (and folds
   // their reduction into a later launch)
   if (dbias && dbias != partials) launch_reduce_partials(partials, grid, C, dbias, st);
@@ -375,24 +377,35 @@ size_t mis_bn_relu_bwd_workspace_bytes(int64_t n_pix, int C) {
   return a > b ? a : b;
 }
 
-int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
-                           const float* gamma, const float* beta, float* sums, void* workspace, mis_stream_t stream) {
+static int bn_bwd_reduce_any(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
+                             const float* gamma, const float* beta, float* sums, void* workspace, mis_stream_t stream,
+                             int relu) {
   MIS_REQUIRE(z && da && mean_rstd && gamma && beta && sums && workspace, "bn_relu_bwd_reduce: null pointer");
   MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_reduce: bad shape");
   if (dtype == MIS_F32) {
     MIS_REQUIRE(C % 4 == 0 ? C / 4 <= 256 : C <= 256, "bn_relu_bwd_reduce: C=%d too large for this layout", C);
-    bwd_reduce_t<float>(z, da, n_pix, C, mean_rstd, gamma, beta, sums, workspace, (hipStream_t)stream);
+    bwd_reduce_t<float>(z, da, n_pix, C, mean_rstd, gamma, beta, sums, workspace, (hipStream_t)stream, relu);
   } else if (dtype == MIS_BF16) {
     MIS_REQUIRE(C % 8 == 0 ? C / 8 <= 256 : C <= 256, "bn_relu_bwd_reduce: C=%d too large for this layout", C);
-    bwd_reduce_t<bf16>(z, da, n_pix, C, mean_rstd, gamma, beta, sums, workspace, (hipStream_t)stream);
+    bwd_reduce_t<bf16>(z, da, n_pix, C, mean_rstd, gamma, beta, sums, workspace, (hipStream_t)stream, relu);
   } else MIS_REQUIRE(false, "bn_relu_bwd_reduce: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("bn_relu_bwd_reduce");
   return MIS_OK;
 }
 
-int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
-                       const float* gamma, const float* beta, const float* sums, void* dz, float* dbias,
-                       void* workspace, mis_stream_t stream) {
+int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
+                           const float* gamma, const float* beta, float* sums, void* workspace, mis_stream_t stream) {
+  return bn_bwd_reduce_any(z, da, dtype, n_pix, C, mean_rstd, gamma, beta, sums, workspace, stream, 1);
+}
+
+int mis_bn_bwd_reduce(const void* z, const void* dy, int dtype, int64_t n_pix, int C, const float* mean_rstd,
+                      const float* gamma, const float* beta, float* sums, void* workspace, mis_stream_t stream) {
+  return bn_bwd_reduce_any(z, dy, dtype, n_pix, C, mean_rstd, gamma, beta, sums, workspace, stream, 0);
+}
+
+static int bn_bwd_dz_any(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
+                         const float* gamma, const float* beta, const float* sums, void* dz, float* dbias,
+                         void* workspace, mis_stream_t stream, int relu) {
   MIS_REQUIRE(z && da && mean_rstd && gamma && beta && sums && dz, "bn_relu_bwd_dz: null pointer");
   MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_dz: bad shape");
   MIS_REQUIRE(!dbias || workspace, "bn_relu_bwd_dz: dbias requested without a workspace");
@@ -400,12 +413,24 @@ int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, 
                   ((((uintptr_t)z | (uintptr_t)da | (uintptr_t)dz) & 15) == 0),
               "bn_relu_bwd_dz: partial rows need 16-byte aligned tensors");
   if (dtype == MIS_F32)
-    bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream);
+    bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream, relu);
   else if (dtype == MIS_BF16)
-    bwd_dz_t<bf16>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream);
+    bwd_dz_t<bf16>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream, relu);
   else MIS_REQUIRE(false, "bn_relu_bwd_dz: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("bn_relu_bwd_dz_kernel");
   return MIS_OK;
+}
+
+int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
+                       const float* gamma, const float* beta, const float* sums, void* dz, float* dbias,
+                       void* workspace, mis_stream_t stream) {
+  return bn_bwd_dz_any(z, da, dtype, n_pix, C, mean_rstd, gamma, beta, sums, dz, dbias, workspace, stream, 1);
+}
+
+int mis_bn_bwd_dz(const void* z, const void* dy, int dtype, int64_t n_pix, int C, const float* mean_rstd,
+                  const float* gamma, const float* beta, const float* sums, void* dz, float* dbias, void* workspace,
+                  mis_stream_t stream) {
+  return bn_bwd_dz_any(z, dy, dtype, n_pix, C, mean_rstd, gamma, beta, sums, dz, dbias, workspace, stream, 0);
 }
 
 int mis_bn_relu_bwd_dz_rows(int dtype, int64_t n_pix, int C) {

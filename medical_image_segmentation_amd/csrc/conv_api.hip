@@ -150,6 +150,52 @@ int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int 
   return conv3x3_direct_wgrad(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, workspace, (hipStream_t)stream);
 }
 
+int mis_conv3x3_dilated_supported(int dtype, int B, int H, int W, int Cin, int Cout, int dilation) {
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
+  if (dilation < 1 || dilation > 3 || force_direct()) return 0;
+  return (use_mfma(dtype, Cin, Cout) && use_mfma(dtype, Cout, Cin) && conv3x3_mfma_supported(dtype, B, H, W, Cin, Cout) &&
+          conv3x3_mfma_supported(dtype, B, H, W, Cout, Cin) && conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout))
+             ? 1 : 0;
+}
+
+int mis_conv3x3_dilated_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout, int dilation) {
+  if (!mis_conv3x3_dilated_supported(dtype, B, H, W, Cin, Cout, dilation)) return 0;
+  return conv3x3_mfma_stats_rows(dtype, B, H, W, Cin, Cout, dilation);
+}
+
+int mis_conv3x3_dilated_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype,
+                            int B, int H, int W, int Cin, int Cout, int dilation, void* z, float* stats,
+                            void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(x && w_packed && z, "conv3x3_dilated_fwd: null pointer");
+  MIS_REQUIRE(!stats || workspace, "conv3x3_dilated_fwd: stats requested without a workspace");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_dilated_fwd: bad dtype %d", dtype);
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1 && (int64_t)B * H * W < ((int64_t)1 << 31),
+              "conv3x3_dilated_fwd: bad shape");
+  if (dilation < 1 || dilation > 3 || force_direct() || !use_mfma(dtype, Cin, Cout)) {
+    mis_set_error("conv3x3_dilated_fwd: %d -> %d channels with dilation %d is not taken by the matrix-core kernels",
+                  Cin, Cout, dilation);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  return conv3x3_mfma_fwd(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, w_packed, bias, dtype, B, H, W,
+                          ConvOut{z, Cout, nullptr, 0}, stats, workspace, (hipStream_t)stream, nullptr, nullptr,
+                          dilation);
+}
+
+int mis_conv3x3_dilated_wgrad(const void* x, const float* x_affine, const void* dz, int dtype, int B, int H, int W,
+                              int Cin, int Cout, int dilation, float* dw, const float* bias_rows, int n_bias_rows,
+                              float* dbias, void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(x && dz && dw && workspace, "conv3x3_dilated_wgrad: null pointer");
+  MIS_REQUIRE(!dbias || (bias_rows && n_bias_rows >= 1), "conv3x3_dilated_wgrad: dbias needs its partial rows");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_dilated_wgrad: bad dtype %d", dtype);
+  if (dilation < 1 || dilation > 3 || force_direct() || !conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout)) {
+    mis_set_error("conv3x3_dilated_wgrad: %d -> %d channels with dilation %d is not taken by the matrix-core kernels",
+                  Cin, Cout, dilation);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  return conv3x3_wgrad_mfma(ConvIn{x, x_affine, Cin, nullptr, nullptr, 0}, dz, dtype, B, H, W, Cout, dw,
+                            BiasRows{bias_rows, n_bias_rows, dbias}, workspace, (hipStream_t)stream, dilation);
+}
+
 int mis_conv3x3_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout) {
   if (B < 1 || H < 1 || W < 1 || Ca < 1 || Cb < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
   if (force_direct()) return 0;

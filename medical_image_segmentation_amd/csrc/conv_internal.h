@@ -6,7 +6,7 @@ size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout);
 // Rows of per-workgroup partial statistics [rows][2][Cout] a forward launch leaves at the start
 // of the workspace (reduced into `stats` unless stats == workspace).
 int conv3x3_direct_stats_rows(int64_t n_pix);
-int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout);
+int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout, int dil = 1);
 // `in_aff` / `x_aff`: optional [2][Cin] (scale, shift) of a lazily stored input activation:
 // the kernel reads relu(x*scale + shift) instead of x (padding stays zero).
 int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const float* bias, int dtype, int B, int H,
@@ -44,7 +44,7 @@ size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int
 // (sum dy, sum dy*xhat) instead of (sum z, sum z^2).  bn_aff: [4][Cout] = scale, shift, mean, rstd.
 int conv3x3_mfma_fwd(const ConvIn& in, const void* wp, const float* bias, int dtype, int B, int H, int W,
                      const ConvOut& out, float* stats, void* workspace, hipStream_t st, const void* bnz = nullptr,
-                     const float* bn_aff = nullptr);
+                     const float* bn_aff = nullptr, int dil = 1);      // dil: tap dilation 1..3 (padding = dil)
 size_t conv3x3_mfma_packed_bytes(int dtype, int Cin, int Cout);
 int conv3x3_mfma_pack(const float* w, int Cw_out, int Cw_in, int transposed, int dtype, void* out, hipStream_t st);
 // both images (forward and transposed = data-gradient operand) of one weight tensor in one launch
@@ -63,4 +63,4 @@ struct BiasRows {
   const float* rows; int n_rows; float* dbias;
 };
 int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, float* dw,
-                       const BiasRows& bias, void* workspace, hipStream_t st);
+                       const BiasRows& bias, void* workspace, hipStream_t st, int dil = 1);

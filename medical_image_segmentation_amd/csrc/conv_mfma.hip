@@ -209,7 +209,9 @@ struct TilePos {
 // and want more waves in flight, the wide ones need the registers
 constexpr int fwd_min_blocks(int nt, int cpg) { return (nt == 4 || nt * cpg >= 6) ? 2 : (nt == 1 && cpg <= 2 ? 4 : 3); }
 
-template <typename T, int NT, int CPG, bool BNS>
+// DIL: dilation of the 3x3 taps (padding = DIL, so the output keeps the input's size): the halo
+// grows to (TH + 2*DIL) x (TW + 2*DIL) and the tap offsets are multiplied by DIL; nothing else changes.
+template <typename T, int NT, int CPG, bool BNS, int DIL = 1>
 __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_mfma_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ wp, const float* __restrict__ bias,
     T* __restrict__ za, T* __restrict__ zb, float* __restrict__ partials, int B, int H, int W, int Cin, int Cs,
@@ -227,8 +229,8 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   constexpr int MT = fwd_mt(NT, CPG);      // tile rows per wave
   constexpr int MX = fwd_mx(NT, CPG), MY = MT / MX;      // a wave's segments: MY rows x MX side by side
   constexpr int TW = 16 * MX, TH = 4 * MY;               // tile width, height
-  constexpr int HW_ = TW + 2;                            // halo width
-  constexpr int HP = (TH + 2) * HW_;                     // halo positions
+  constexpr int HW_ = TW + 2 * DIL;                      // halo width
+  constexpr int HP = (TH + 2 * DIL) * HW_;               // halo positions
   constexpr int HALO_VECS = HP * CPG;
   constexpr int HALO_IT = (HALO_VECS + CM_THREADS - 1) / CM_THREADS;
   constexpr int W_VECS = NS * NT * 64;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
       int g = 4 * s + kg;
       int tap = g / CPG;
       if (tap > 8) tap = 8;                        // padded group: weights are zero, read finite data
-      tap_addr[s] = halo_addr<CPG>((tap / 3) * HW_ + (tap % 3), g % CPG);
+      tap_addr[s] = halo_addr<CPG>(((tap / 3) * HW_ + (tap % 3)) * DIL, g % CPG);
     }
   }
   // LDS byte address of this lane's first fragment: wave's first row, lane's column (and group)
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   // requested while tile t computes, so a load has two tile times to arrive.  Measured on the
   // write-heavy layers: reads queued behind a saturated store path otherwise stall the pipeline
   // (time = read phase + write phase instead of their maximum).
-  constexpr bool DEEP = (CPG < 4) && (MIS_DEEP != 0) && !BNS;      // (the fused-sums epilogue twice over would spill)
+  constexpr bool DEEP = (CPG < 4) && (MIS_DEEP != 0) && !BNS && DIL == 1;   // (the fused-sums epilogue twice over would spill)
   u32x4 hreg[HALO_IT], hregB[DEEP ? HALO_IT : 1], wreg[W_IT];
 #define HREG hreg
   const __amdgpu_buffer_rsrc_t wrs =
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   const int img_bytes = H * W * Cs * (int)sizeof(T);
 #define LOAD_HALO(P, CHUNK, LIVE)                                                                        \
   {                                                                                                      \
-    const int xo_ = (P).tx * TW - 1, yo_ = (P).ty * TH - 1;                                              \
+    const int xo_ = (P).tx * TW - DIL, yo_ = (P).ty * TH - DIL;                                          \
     const int x0_ = ((LIVE) && !(MIS_DBG & 4)) ? xo_ : -(1 << 29);                                       \
     const bool sb_ = (CHUNK) >= n_chunks_a;                                                              \
     const T* xs_ = sb_ ? xb : xa;                                                                        \
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
       if (((CHUNK) >= n_chunks_a) ? (affb != nullptr) : (affa != nullptr)) {                             \
         const int v = tid + i * CM_THREADS;                                                              \
         const int pos = v / CPG, cg = v % CPG;                                                           \
-        const int gy = (P).ty * TH - 1 + pos / HW_, gx = (P).tx * TW - 1 + pos % HW_;                    \
+        const int gy = (P).ty * TH - DIL + pos / HW_, gx = (P).tx * TW - DIL + pos % HW_;                \
         const int c = (CHUNK) * KC + cg * G;                                                             \
         if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)                                    \
           val = affine_relu_raw<T>(val, aff + c, aff + Cin + c);                                         \
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     _Pragma("unroll") for (int m = 0; m < MT; m++) {                                                     \
       int a_;                                                                                            \
       const int mp_ = (m / MX) * HW_ + (m % MX) * 16;     /* segment m: row m/MX, columns 16*(m%MX).. */ \
-      if constexpr (CPG == 4) a_ = frag_base + halo_addr<CPG>(mp_ + ((S) / 3) * HW_ + ((S) % 3), 0);     \
+      if constexpr (CPG == 4) a_ = frag_base + halo_addr<CPG>(mp_ + (((S) / 3) * HW_ + ((S) % 3)) * DIL, 0); \
       else a_ = frag_base + tap_addr[CPG == 4 ? 0 : (S)] + halo_addr<CPG>(mp_, 0);                       \
       xa[BUF][m] = *reinterpret_cast<const Frag*>(halo + a_);                                            \
     }                                                                                                    \
@@ -708,7 +710,7 @@ int fwd_resident(int NT, int CPG, size_t lds) {
 // Ca_in: channels of the first input tensor (== Cin for one tensor); Cout_a: channels of the
 // first output tensor (== Cout for one tensor).
 template <typename T>
-bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1, int Cout_a = -1) {
+bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1, int Cout_a = -1, int dil = 1) {
   constexpr int G = Mf<T>::G;
   if (Cin % G != 0 || Cout % 4 != 0 || Cin < G) return false;
   if ((int64_t)Cin * Cout >= ((int64_t)1 << 26)) return false;      // packed image indices stay below 2^31
@@ -751,7 +753,8 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
   p.tiles_x = (W + TW - 1) / TW;
   p.tiles_y = (H + TH - 1) / TH;
   p.n_tiles = B * p.tiles_x * p.tiles_y;
-  p.lds = (size_t)(TH + 2) * HW_ * (p.CPG == 4 ? 96 : (p.CPG | 1) * 16) + 16 + (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
+  p.lds = (size_t)(TH + 2 * dil) * (TW + 2 * dil) * (p.CPG == 4 ? 96 : (p.CPG | 1) * 16) + 16 +
+          (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
           (size_t)p.NT * 16 * 4 + 2 * (size_t)Cin * 4 + 4 * (size_t)p.NT * 16 * 4;
   // Total workgroups per launch: as many as are resident at once on 256 CUs, so the persistent
   // workgroups run as one round (a second, partly filled round costs a whole tile range: 10-25 %
@@ -780,11 +783,15 @@ struct FwdArgs {
   int B, H, W;
   const void* bnz;          // BatchNorm-backward sums of relu(bn(bnz)) with the output as gradient (or null)
   const float* bn_aff;      // its [4][Cout] (scale, shift, mean, rstd)
+  int dil;                  // dilation of the taps: 1, 2 or 3
 };
 
 template <typename T, int NT, int CPG>
 void launch_fwd_k(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
-  auto kfn = a.bnz ? conv3x3_mfma_kernel<T, NT, CPG, true> : conv3x3_mfma_kernel<T, NT, CPG, false>;
+  auto kfn = a.bnz ? conv3x3_mfma_kernel<T, NT, CPG, true, 1>
+             : a.dil == 2 ? conv3x3_mfma_kernel<T, NT, CPG, false, 2>
+             : a.dil == 3 ? conv3x3_mfma_kernel<T, NT, CPG, false, 3>
+                          : conv3x3_mfma_kernel<T, NT, CPG, false, 1>;
   if (p.lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
   const int Cin = a.in.channels(), Cout = a.out.channels();
@@ -807,14 +814,19 @@ void launch_fwd_cpg(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
 
 template <typename T>
 int run_fwd(const ConvIn& in, const void* wp, const float* bias, int B, int H, int W, const ConvOut& out,
-            float* stats, void* workspace, hipStream_t st, const void* bnz = nullptr, const float* bn_aff = nullptr) {
+            float* stats, void* workspace, hipStream_t st, const void* bnz = nullptr, const float* bn_aff = nullptr,
+            int dil = 1) {
   FwdPlan p;
   const int Cin = in.channels(), Cout = out.channels();
-  if (!plan_fwd<T>(B, H, W, Cin, Cout, p, in.Ca, out.Ca)) {
+  if (dil < 1 || dil > 3 || (dil != 1 && bnz)) {
+    mis_set_error("conv3x3_mfma: dilation %d not supported here (1..3; the fused BatchNorm sums only with 1)", dil);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  if (!plan_fwd<T>(B, H, W, Cin, Cout, p, in.Ca, out.Ca, dil)) {
     mis_set_error("conv3x3_mfma: unsupported shape Cin=%d+%d Cout=%d+%d", in.Ca, in.Cb, out.Ca, out.Cb);
     return MIS_ERR_UNSUPPORTED;
   }
-  FwdArgs a{in, out, wp, bias, stats ? (float*)workspace : nullptr, B, H, W, bnz, bn_aff};
+  FwdArgs a{in, out, wp, bias, stats ? (float*)workspace : nullptr, B, H, W, bnz, bn_aff, dil};
   switch (p.NT) {
     case 1: launch_fwd_cpg<T, 1>(p, a, st); break;
     case 2: launch_fwd_cpg<T, 2>(p, a, st); break;
@@ -848,9 +860,10 @@ bool conv3x3_mfma_split_supported(int dtype, int Cin, int Ca, int Cb) {
                            : plan_fwd<float>(1, 16, 16, Cin, Ca + Cb, p, -1, Ca);
 }
 
-int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout) {
+int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout, int dil) {
   FwdPlan p;
-  const bool ok = dtype == MIS_BF16 ? plan_fwd<bf16>(B, H, W, Cin, Cout, p) : plan_fwd<float>(B, H, W, Cin, Cout, p);
+  const bool ok = dtype == MIS_BF16 ? plan_fwd<bf16>(B, H, W, Cin, Cout, p, -1, -1, dil)
+                                    : plan_fwd<float>(B, H, W, Cin, Cout, p, -1, -1, dil);
   return ok ? p.grid_x : 0;
 }
 
@@ -934,9 +947,9 @@ int conv3x3_mfma_pack_multi(const mis_pack_job* jobs_dev, int n_jobs, int total_
 
 int conv3x3_mfma_fwd(const ConvIn& in, const void* wp, const float* bias, int dtype, int B, int H, int W,
                      const ConvOut& out, float* stats, void* workspace, hipStream_t st, const void* bnz,
-                     const float* bn_aff) {
-  if (dtype == MIS_BF16) return run_fwd<bf16>(in, wp, bias, B, H, W, out, stats, workspace, st, bnz, bn_aff);
-  return run_fwd<float>(in, wp, bias, B, H, W, out, stats, workspace, st, bnz, bn_aff);
+                     const float* bn_aff, int dil) {
+  if (dtype == MIS_BF16) return run_fwd<bf16>(in, wp, bias, B, H, W, out, stats, workspace, st, bnz, bn_aff, dil);
+  return run_fwd<float>(in, wp, bias, B, H, W, out, stats, workspace, st, bnz, bn_aff, dil);
 }
 
 // =====================================================================================
@@ -993,7 +1006,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int lane_of
 
 // The four-wave (light-channel) variants are bound by memory latency: three resident workgroups per
 // CU (<= 168 registers) keep a third more bytes in flight than two and run 15-25% faster.
-template <typename T, int MTO, int NTI, int WCO, int WCI, int WK>
+template <typename T, int MTO, int NTI, int WCO, int WCI, int WK, int DIL = 1>
 __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x3_wgrad_mfma_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, int Ca, const T* __restrict__ dz, float* __restrict__ slab,
     int B, int H, int W, int Cin, int Cout, int n_ci_blocks, int tiles_x, int tiles_y, int n_tiles,
@@ -1001,8 +1014,8 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   constexpr int NTHR = 64 * WCO * WCI * WK;
   constexpr int G = Mf<T>::G;
   constexpr int TH = WgT<T>::TH;
-  constexpr int HWW = WG_TW + 2;                 // halo width 34
-  constexpr int PH = (TH + 2) * HWW;             // halo positions
+  constexpr int HWW = WG_TW + 2 * DIL;           // halo width (34 without dilation)
+  constexpr int PH = (TH + 2 * DIL) * HWW;       // halo positions
   constexpr int PZ = TH * WG_TW;                 // dz positions
   constexpr int CTO = WCO * MTO * 16, CTI = WCI * NTI * 16;
   constexpr int XVP = CTI / G, ZVP = CTO / G;    // 16-byte vectors per position
@@ -1086,10 +1099,10 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
         (void*)(x + (int64_t)(P).b * H * W * Csrc), 0, ximg_bytes, 0x00020000);                         \
     const __amdgpu_buffer_rsrc_t zrs_ = __builtin_amdgcn_make_buffer_rsrc(                              \
         (void*)(dz + (int64_t)(P).b * H * W * Cout), 0, zimg_bytes, 0x00020000);                        \
-    const unsigned xb_ = (unsigned)((((y0_ - 1) * W + xo_ - 1) * Csrc) * (int)sizeof(T));               \
+    const unsigned xb_ = (unsigned)((((y0_ - DIL) * W + xo_ - DIL) * Csrc) * (int)sizeof(T));           \
     const unsigned zb_ = (unsigned)(((y0_ * W + xo_) * Cout) * (int)sizeof(T));                         \
     _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                   \
-      const bool ok = (unsigned)(x0_ - 1 + x_px[i]) < (unsigned)W;                                      \
+      const bool ok = (unsigned)(x0_ - DIL + x_px[i]) < (unsigned)W;                                    \
       xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs_, (int)(ok ? xb_ + x_rel[i] : OOB), 0, 0);      \
     }                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < ZIT; i++) {                                                   \
@@ -1103,7 +1116,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
       u32x4 val = xr[i];                                                                                \
       if (x_aff) {                                                                                      \
         const int v = tid + i * NTHR, pos = v / XVP, cv = v % XVP;                                      \
-        const int gy = (P).ty * TH - 1 + pos / HWW, gx = (P).tx * WG_TW - 1 + pos % HWW;                \
+        const int gy = (P).ty * TH - DIL + pos / HWW, gx = (P).tx * WG_TW - DIL + pos % HWW;            \
         if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && cl0 + cv * G < Csrc)            \
           val = affine_relu_raw<T>(val, aff + cv * G, aff + CTI + cv * G);                              \
       }                                                                                                 \
@@ -1151,7 +1164,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
         for (int t = 0; t < 9; t++) {
 #pragma unroll
           for (int ni = 0; ni < NTI; ni++) {
-            const bf16x8 bq = tr_frag<RSX>(xh, offx, (r * HWW + (t / 3) * HWW + (t % 3)) * RSX + ni * 32);
+            const bf16x8 bq = tr_frag<RSX>(xh, offx, (r * HWW + ((t / 3) * HWW + (t % 3)) * DIL) * RSX + ni * 32);
 #pragma unroll
             for (int mo = 0; mo < MTO; mo++)
               acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mo], bq, acc[t][mo][ni], 0, 0, 0);
@@ -1171,7 +1184,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
           for (int t = 0; t < 9; t++) {
 #pragma unroll
             for (int ni = 0; ni < NTI; ni++) {
-              const int pos = (r + t / 3) * HWW + (t % 3) + px, c = (wci * NTI + ni) * 16 + (lane & 15);
+              const int pos = (r + (t / 3) * DIL) * HWW + (t % 3) * DIL + px, c = (wci * NTI + ni) * 16 + (lane & 15);
               const float bq = *reinterpret_cast<const float*>(xh + pos * RSX + c * 4);
 #pragma unroll
               for (int mo = 0; mo < MTO; mo++)
@@ -1275,7 +1288,7 @@ struct WgPlan {
 };
 
 template <typename T>
-bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1) {
+bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1, int dil = 1) {
   constexpr int G = Mf<T>::G;
   constexpr int TH = WgT<T>::TH;
   if (Cin % G != 0 || Cout % G != 0) return false;
@@ -1314,7 +1327,7 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1) 
   if (ns < 1) ns = 1;
   if (nout > 1 && ns >= 8) ns &= ~7;          // whole groups of 8: the kernel's XCD-aware id mapping
   p.nsplit = ns;
-  const size_t tiles = (size_t)(TH + 2) * (WG_TW + 2) * padded_row_bytes(p.CTI * (int)sizeof(T)) + 16 +
+  const size_t tiles = (size_t)(TH + 2 * dil) * (WG_TW + 2 * dil) * padded_row_bytes(p.CTI * (int)sizeof(T)) + 16 +
                        (size_t)TH * WG_TW * padded_row_bytes(p.CTO * (int)sizeof(T)) + 16 + 2 * (size_t)p.CTI * 4;
   // K-split reduction scratch: one 9 x (tiles per wave) x 1 KiB region per (co,ci) wave group
   const size_t redb = (size_t)9 * (p.CTO / 16) * (p.CTI / 16) * 64 * 16;
@@ -1324,10 +1337,14 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1) 
 
 template <typename T>
 int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, float* dw, const BiasRows& bias,
-              void* workspace, hipStream_t st) {
+              void* workspace, hipStream_t st, int dil) {
   WgPlan p;
   const int Cin = in.channels();
-  if (!plan_wgrad<T>(B, H, W, Cin, Cout, p, in.Ca)) {
+  if (dil < 1 || dil > 3) {
+    mis_set_error("conv3x3_wgrad_mfma: dilation %d not supported (1..3)", dil);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  if (!plan_wgrad<T>(B, H, W, Cin, Cout, p, in.Ca, dil)) {
     mis_set_error("conv3x3_wgrad_mfma: unsupported shape Cin=%d Cout=%d", Cin, Cout);
     return MIS_ERR_UNSUPPORTED;
   }
@@ -1336,7 +1353,9 @@ int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, f
   dim3 grid(p.nsplit * nout_blocks);
 #define WG_LAUNCH(MTO, NTI, WCO, WCI, WK)                                                                  \
   {                                                                                                        \
-    auto kfn = conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK>;                                       \
+    auto kfn = dil == 2 ? conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK, 2>                          \
+               : dil == 3 ? conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK, 3>                        \
+                          : conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK, 1>;                       \
     if (p.lds > 48 * 1024)                                                                                 \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
     kfn<<<grid, 64 * WCO * WCI * WK, p.lds, st>>>((const T*)in.xa, (const T*)in.xb, in.Ca, (const T*)dz, slab, B, \
@@ -1389,7 +1408,7 @@ bool conv3x3_wgrad_mfma_cat_supported(int dtype, int B, int H, int W, int Ca, in
 }
 
 int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, float* dw,
-                       const BiasRows& bias, void* workspace, hipStream_t st) {
-  if (dtype == MIS_BF16) return run_wgrad<bf16>(in, dz, B, H, W, Cout, dw, bias, workspace, st);
-  return run_wgrad<float>(in, dz, B, H, W, Cout, dw, bias, workspace, st);
+                       const BiasRows& bias, void* workspace, hipStream_t st, int dil) {
+  if (dtype == MIS_BF16) return run_wgrad<bf16>(in, dz, B, H, W, Cout, dw, bias, workspace, st, dil);
+  return run_wgrad<float>(in, dz, B, H, W, Cout, dw, bias, workspace, st, dil);
 }

@@ -279,7 +279,7 @@ def cat_supported(x, x2, Cout):
     return bool(query("mis_conv3x3_cat_supported", _dt(x), B, H, W, Ca, x2.shape[1], Cout))
 
 
-def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None, x2=None, x2_ss=None):
+def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None, x2=None, x2_ss=None, dilation=1):
     """z = conv3x3(act([x | x2])) + bias; optionally the per-channel (sum, sumsq) of z.
     act(t) = relu(t*scale + shift) per tensor when its ss ([2, C]) is given (lazy activation),
     else t.  x2 (optional) supplies the input channels after x's: the concatenation is virtual."""
@@ -288,17 +288,23 @@ def conv3x3_raw(x, w_packed, bias, Cout, want_stats, x_ss=None, x2=None, x2_ss=N
     Cin = Ca + Cb
     z = _empty_act(B, Cout, H, W, x)
     ws = workspace(query("mis_conv3x3_workspace_bytes", B, H, W, Cin, Cout), x.device)
+    if dilation != 1 and x2 is not None:
+        raise ValueError("dilated convs take one input tensor")
     if want_stats == "partial":
         # un-reduced per-workgroup rows stay at the head of the workspace for bn_finalize, which must
         # be the next user of the workspace on this stream: (tensor, rows)
         stats = ws
-        rows = query("mis_conv3x3_stats_rows", _dt(x), B, H, W, Cin, Cout)
+        rows = (query("mis_conv3x3_stats_rows", _dt(x), B, H, W, Cin, Cout) if dilation == 1 else
+                query("mis_conv3x3_dilated_stats_rows", _dt(x), B, H, W, Cin, Cout, dilation))
     else:
         stats = torch.empty((2, Cout), dtype=torch.float32, device=x.device) if want_stats else None
     es = x.element_size()
     with _prof("conv3x3_fwd", 18 * B * H * W * Cin * Cout, (B * H * W * (Cin + Cout) + 9 * Cin * Cout) * es,
-               f"{Cin}->{Cout}@{H}x{W}"):
-        if x2 is None:
+               f"{Cin}->{Cout}@{H}x{W}" + (f" d{dilation}" if dilation != 1 else "")):
+        if dilation != 1:
+            call("mis_conv3x3_dilated_fwd", x.data_ptr(), _p(x_ss), w_packed.data_ptr(), _p(bias), _dt(x), B, H, W, Cin,
+                 Cout, dilation, z.data_ptr(), _p(stats), ws.data_ptr(), _stream())
+        elif x2 is None:
             call("mis_conv3x3_fwd", x.data_ptr(), _p(x_ss), w_packed.data_ptr(), _p(bias),
                  _dt(x), B, H, W, Cin, Cout, z.data_ptr(), _p(stats), ws.data_ptr(), _stream())
         else:
@@ -321,7 +327,7 @@ def conv3x3_split_raw(x, w_packed, Ca, Cb):
     return za, zb
 
 
-def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None, bias_rows=None):
+def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None, bias_rows=None, dilation=1):
     """dW of the conv; with `bias_rows` = (rows tensor [n, Cout], n) also dbias = column sums of
     the rows, reduced inside the same launch.  Returns dw, or (dw, dbias)."""
     B, Ca, H, W = x.shape
@@ -335,8 +341,12 @@ def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None, bias_rows=None):
         rows, n_rows = bias_rows
         dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
     with _prof("conv3x3_wgrad", 18 * B * H * W * Cin * Cout,
-               B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout, f"{Cin}->{Cout}@{H}x{W}"):
-        if x2 is None:
+               B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout,
+               f"{Cin}->{Cout}@{H}x{W}" + (f" d{dilation}" if dilation != 1 else "")):
+        if dilation != 1:
+            call("mis_conv3x3_dilated_wgrad", x.data_ptr(), _p(x_ss), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout,
+                 dilation, dw.data_ptr(), _p(rows), n_rows, _p(dbias), ws.data_ptr(), _stream())
+        elif x2 is None:
             call("mis_conv3x3_wgrad", x.data_ptr(), _p(x_ss), dz.data_ptr(), _dt(x), B, H, W, Cin, Cout,
                  dw.data_ptr(), _p(rows), n_rows, _p(dbias), ws.data_ptr(), _stream())
         else:
@@ -419,8 +429,12 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x_ss, x2, x2_ss, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps,
-                momentum):
-        """x2 (optional, lazy or plain like x): the input is the virtual concatenation [x | x2]."""
+                momentum, relu=True, dilation=1):
+        """x2 (optional, lazy or plain like x): the input is the virtual concatenation [x | x2].
+        relu=False: BatchNorm without a ReLU of its own (ResDConv's `c1` and `cbr3`, modules.py:432-433,
+        444-445): ss is then the affine of bn(z) and the incoming gradient is that of the BatchNorm
+        output; only a consumer that knows (functional.add_bn_relu) may read such a pair.
+        dilation: 1, 2 or 3 (padding = dilation), modules.py:440-445."""
         _check_act(x)
         B, Ca, H, W = x.shape
         Cin = Ca
@@ -441,8 +455,10 @@ class ConvBnReluFn(torch.autograd.Function):
             wf, ctx.wt = pack_weights_pair(weight.detach(), x.dtype)
         else:
             wf, ctx.wt = pack_weights(weight.detach(), x.dtype), None
+        if dilation != 1 and not query("mis_conv3x3_dilated_supported", _dt(x), B, H, W, Cin, Cout, dilation):
+            raise RuntimeError(f"dilated conv {Cin}->{Cout} (dilation {dilation}) is not taken by the matrix-core kernels")
         z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout,
-                               "partial" if training else False, x_ss, x2, x2_ss)
+                               "partial" if training else False, x_ss, x2, x2_ss, dilation)
         # the lazy handle: rows (scale, shift) are what consumers apply; rows (mean, rstd) ride along
         # for the backward pass (this layer's, possibly fused into the consumer's backward kernel)
         ss = torch.empty((4, Cout), dtype=torch.float32, device=x.device)
@@ -462,13 +478,14 @@ class ConvBnReluFn(torch.autograd.Function):
         ctx.save_for_backward(x, x_ss, x2, x2_ss, z, weight, gamma, beta, ss)
         ctx.training = training
         ctx.has_bias = bias is not None
+        ctx.relu, ctx.dilation = bool(relu), int(dilation)
         ctx.mark_non_differentiable(ss)
         return z, ss
 
     @staticmethod
     def backward(ctx, da, _dss):
         if da is None:
-            return (None,) * 14
+            return (None,) * 16
         x, x_ss, x2, x2_ss, z, weight, gamma, beta, ss = ctx.saved_tensors
         mr = ss[2:]
         B, Ca, H, W = x.shape
@@ -477,14 +494,15 @@ class ConvBnReluFn(torch.autograd.Function):
         st = _stream()
         # (sum dy, sum dy*xhat): already produced by the kernel that wrote `da` when that kernel had
         # both z and da in registers (max-pool backward, 1x1-conv backward), else one pass over (z, da)
-        sums = take_bn_sums(da, z)
+        relu, dil = ctx.relu, ctx.dilation
+        sums = take_bn_sums(da, z) if relu else None       # (the fused sums carry the ReLU mask)
         da = to_act(da, x.dtype)
         ws = workspace(query("mis_bn_relu_bwd_workspace_bytes", n_pix, Cout), x.device)
         if sums is None:
             sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
             with _prof("bn_relu_bwd_reduce", 0, 2 * z.numel() * z.element_size()):
-                call("mis_bn_relu_bwd_reduce", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
-                     gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ws.data_ptr(), st)
+                call("mis_bn_relu_bwd_reduce" if relu else "mis_bn_bwd_reduce", z.data_ptr(), da.data_ptr(), _dt(x),
+                     n_pix, Cout, mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), ws.data_ptr(), st)
         dgamma, dbeta = sums[1], sums[0]          # rows of one buffer; nothing below writes it
         # eval mode: statistics are constants, so the two projection terms vanish
         proj = sums if ctx.training else torch.zeros_like(sums)
@@ -503,24 +521,25 @@ class ConvBnReluFn(torch.autograd.Function):
         elif want_db:
             dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
         with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
-            call("mis_bn_relu_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout, mr.data_ptr(),
+            call("mis_bn_relu_bwd_dz" if relu else "mis_bn_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout,
+                 mr.data_ptr(),
                  gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
                  rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
         dx = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
             wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
             if x2 is None:
-                dx = _dgrad_with_bn_sums(dz, wd, x, x_ss) if FUSE_BN_SUMS else None
+                dx = _dgrad_with_bn_sums(dz, wd, x, x_ss) if (FUSE_BN_SUMS and dil == 1) else None
                 if dx is None:
-                    dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
+                    dx, _ = conv3x3_raw(dz, wd, None, Cin, False, dilation=dil)
             else:
                 dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
         dw = None
         if rows is not None:
-            dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows))
+            dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=dil)
         elif want_dw:
-            dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss)
-        return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
+            dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=dil)
+        return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class MaterializeFn(torch.autograd.Function):
@@ -995,3 +1014,148 @@ class DiceLossFn(torch.autograd.Function):
         if dlogits.dtype != ctx.in_dtype:
             dlogits = dlogits.to(ctx.in_dtype)
         return dlogits, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# RDAM_UNet pieces (model/rdam_unet.py, model/utils/modules.py:426-453, model/utils/attention.py:147-190)
+# ---------------------------------------------------------------------------
+def conv_bn(x, x_ss, weight, bias, bn, training, relu=True, dilation=1, x2=None, x2_ss=None):
+    """conv3x3 (any dilation 1..3, explicit [Cout, Cin, 3, 3] weight) + BatchNorm2d [+ ReLU] -> (z, ss)."""
+    momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
+    return ConvBnReluFn.apply(x, x_ss, x2, x2_ss, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                              bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum), bool(relu),
+                              int(dilation))
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """nn.Conv2d(Cin, Cout, 3, padding=1) with bias and nothing after it (RDAM_UNet.encoder1 /
+    decoder4, rdam_unet.py:22,52): (x, x_ss) [| (x2, x2_ss)] -> plain z."""
+
+    @staticmethod
+    def forward(ctx, x, x_ss, x2, x2_ss, weight, bias):
+        _check_act(x)
+        Cout = weight.shape[0]
+        pre = packed_for(weight, x.dtype)
+        need_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
+        if pre is not None:
+            wf, ctx.wt = pre
+        elif need_dx:
+            wf, ctx.wt = pack_weights_pair(weight.detach(), x.dtype)
+        else:
+            wf, ctx.wt = pack_weights(weight.detach(), x.dtype), None
+        z, _ = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout, False, x_ss, x2, x2_ss)
+        ctx.save_for_backward(x, x_ss, x2, x2_ss, weight)
+        ctx.has_bias = bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, x_ss, x2, x2_ss, weight = ctx.saved_tensors
+        B, Ca, H, W = x.shape
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        dz = to_act(dz, x.dtype)
+        dx = dx2 = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
+            wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
+            if x2 is None:
+                dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
+            else:
+                dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
+        dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss) if ctx.needs_input_grad[4] else None
+        db = channel_sum_raw(dz) if (ctx.has_bias and ctx.needs_input_grad[5]) else None
+        return dx, None, dx2, None, dw, db
+
+
+class AddBnReluFn(torch.autograd.Function):
+    """relu(bn_a(za) + bn_b(zb)) from two (conv output, BatchNorm affine) pairs produced with
+    relu=False — the tail of ResDConv.forward (modules.py:447-453).  Plain output; the backward
+    hands dout*[out > 0] to both BatchNorm outputs."""
+
+    @staticmethod
+    def forward(ctx, za, ssa, zb, ssb):
+        _check_act(za, "za")
+        _check_act(zb, "zb")
+        if za.shape != zb.shape or za.dtype != zb.dtype:
+            raise ValueError(f"shapes differ: {tuple(za.shape)} vs {tuple(zb.shape)}")
+        B, Cc, H, W = za.shape
+        out = torch.empty_like(za)
+        with _prof("add_bn_relu_fwd", 0, 3 * za.numel() * za.element_size()):
+            call("mis_add_bn_relu_fwd", za.data_ptr(), ssa.data_ptr(), zb.data_ptr(), ssb.data_ptr(), _dt(za),
+                 B * H * W, Cc, out.data_ptr(), _stream())
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, = ctx.saved_tensors
+        B, Cc, H, W = out.shape
+        dout = to_act(dout, out.dtype)
+        g = torch.empty_like(out)
+        with _prof("relu_mask_bwd", 0, 3 * out.numel() * out.element_size()):
+            call("mis_relu_mask_bwd", out.data_ptr(), dout.data_ptr(), _dt(out), B * H * W, Cc, g.data_ptr(), _stream())
+        return g, None, g, None
+
+
+def add_bn_relu(a, b):
+    """a, b: (z, ss) pairs from conv_bn(..., relu=False)."""
+    return AddBnReluFn.apply(a[0], a[1], b[0], b[1])
+
+
+class WindowSumsFn(torch.autograd.Function):
+    """x [B, C, H, W] -> S float32 [B, C, 9]: per (sample, channel) the sum of x over the pixels
+    each tap of a zero-padded 3x3 conv reads, so that avgpool(conv3x3(x)) = bias + W.S/(H*W)
+    without running the conv (MDAM's squeeze path, attention.py:184-185)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _check_act(x)
+        B, Cc, H, W = x.shape
+        S = torch.empty((B, Cc, 9), dtype=torch.float32, device=x.device)
+        ws = workspace(query("mis_mdam_workspace_bytes", B, Cc), x.device)
+        with _prof("mdam_window_sums", 0, x.numel() * x.element_size()):
+            call("mis_mdam_window_sums", x.data_ptr(), _dt(x), B, H, W, Cc, S.data_ptr(), ws.data_ptr(), _stream())
+        ctx.dims = (B, Cc, H, W)
+        ctx.meta = (x.dtype, x.device)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        B, Cc, H, W = ctx.dims
+        dx = torch.empty((B, Cc, H, W), dtype=ctx.meta[0], device=ctx.meta[1], memory_format=torch.channels_last)
+        dS = dS.to(torch.float32).contiguous()
+        with _prof("mdam_window_sums_bwd", 0, dx.numel() * dx.element_size()):
+            call("mis_mdam_window_sums_bwd", dS.data_ptr(), _dt(dx), B, H, W, Cc, dx.data_ptr(), _stream())
+        return dx
+
+
+class ChannelScaleFn(torch.autograd.Function):
+    """x * s[b, c] (s float32 [B, C]): `group_x * weights.sigmoid()` of attention.py:189."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        _check_act(x)
+        B, Cc, H, W = x.shape
+        s = s.to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        with _prof("channel_scale", 0, 2 * x.numel() * x.element_size()):
+            call("mis_channel_scale", x.data_ptr(), s.data_ptr(), _dt(x), B, H * W, Cc, out.data_ptr(), _stream())
+        ctx.save_for_backward(x, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, s = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        dout = to_act(dout, x.dtype)
+        dx = ds = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with _prof("channel_scale", 0, 2 * x.numel() * x.element_size()):
+                call("mis_channel_scale", dout.data_ptr(), s.data_ptr(), _dt(x), B, H * W, Cc, dx.data_ptr(), _stream())
+        if ctx.needs_input_grad[1]:
+            ds = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+            ws = workspace(query("mis_mdam_workspace_bytes", B, Cc), x.device)
+            with _prof("channel_dot", 0, 2 * x.numel() * x.element_size()):
+                call("mis_channel_dot", x.data_ptr(), dout.data_ptr(), _dt(x), B, H * W, Cc, ds.data_ptr(),
+                     ws.data_ptr(), _stream())
+        return dx, ds

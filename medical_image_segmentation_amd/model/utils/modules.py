@@ -1,5 +1,5 @@
-"""DoubleConv, DWConv and AMSFN — drop-ins for the reference's model/utils/modules.py:78-116,
-52-77 and 791-887.
+"""DoubleConv, DWConv, AMSFN and ResDConv — drop-ins for the reference's model/utils/modules.py:78-116,
+52-77, 791-887 and 426-471.
 
 Same constructors, same children (`cbr1`, `cbr2` = Sequential(conv, bn, relu), ...) and therefore
 the same state_dict keys; the forwards run the fused gfx950 kernels instead of ATen.
@@ -124,6 +124,49 @@ class AMSFN(nn.Module):
     def forward(self, x):
         z, ss = self.forward_lazy(F_.to_act(x))
         return F_.materialize(z, ss)
+
+    def _initialize_weights(self, init_gain=0.02):
+        _init_like_reference(self)
+
+
+class ResDConv(nn.Module):
+    """Residual block of RDAM_UNet (modules.py:426-453): three chained 3x3 convs with dilations 1, 2, 3
+    (each + BN, the first two + ReLU) plus a 1x1 conv + BN shortcut; out = relu(main + shortcut).
+    Same children (`c1`, `relu`, `cbr1`, `cbr2`, `cbr3`) and state_dict keys.  The dilated convs run
+    on the matrix-core kernels with dilated taps, the 1x1 shortcut as a centre-tap 3x3; the two
+    BatchNorm applications, the addition and the ReLU are one pass."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        if mid_channels is None:
+            mid_channels = in_channels // 2
+        self.c1 = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1), nn.BatchNorm2d(out_channels))
+        self.relu = nn.ReLU(inplace=True)
+        self.cbr1 = nn.Sequential(nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1),
+                                  nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True))
+        self.cbr2 = nn.Sequential(nn.Conv2d(mid_channels, mid_channels, kernel_size=3, padding=2, dilation=2),
+                                  nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True))
+        self.cbr3 = nn.Sequential(nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=3, dilation=3),
+                                  nn.BatchNorm2d(out_channels))
+        _init_like_reference(self)
+
+    def two_inputs_supported(self, skip):
+        """Whether both convs that read the block's input take it as two tensors [up | skip]."""
+        return (F_.cat_supported(skip, skip, self.c1[0].out_channels)
+                and F_.cat_supported(skip, skip, self.cbr1[0].out_channels))
+
+    def forward_plain(self, x, x_ss=None, x2=None, x2_ss=None):
+        """(x, x_ss) [| (x2, x2_ss)] lazy or plain -> the block's activation (a plain tensor)."""
+        t = self.training
+        re = F_.conv_bn(x, x_ss, F_.pointwise_as_3x3(self.c1[0].weight), self.c1[0].bias, self.c1[1], t, relu=False,
+                        x2=x2, x2_ss=x2_ss)
+        y = F_.conv_bn(x, x_ss, self.cbr1[0].weight, self.cbr1[0].bias, self.cbr1[1], t, x2=x2, x2_ss=x2_ss)
+        y = F_.conv_bn(*y, self.cbr2[0].weight, self.cbr2[0].bias, self.cbr2[1], t, dilation=2)
+        y = F_.conv_bn(*y, self.cbr3[0].weight, self.cbr3[0].bias, self.cbr3[1], t, relu=False, dilation=3)
+        return F_.add_bn_relu(y, re)
+
+    def forward(self, x):
+        return self.forward_plain(F_.to_act(x))
 
     def _initialize_weights(self, init_gain=0.02):
         _init_like_reference(self)

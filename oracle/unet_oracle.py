@@ -258,6 +258,72 @@ def a_unet_forward(x, state, training=True, update_stats=True):
     return dc(d, "out_conv")
 
 
+def _bn(z, state, bn_prefix, training, update_stats):
+    """BatchNorm2d without an activation, parameters under `bn_prefix`."""
+    g, b = state[bn_prefix + ".weight"], state[bn_prefix + ".bias"]
+    if training:
+        y, mean, var = batchnorm_train(z, g, b)
+        if update_stats:
+            update_running_stats(state, bn_prefix, mean, var, z.shape[0] * z.shape[2] * z.shape[3])
+        return y
+    return batchnorm_eval(z, g, b, state[bn_prefix + ".running_mean"], state[bn_prefix + ".running_var"])
+
+
+def res_dconv(x, state, prefix, training=True, update_stats=True):
+    """ResDConv.forward — modules.py:447-453: shortcut c1 = BN(conv1x1(x)); main path conv3x3 d=1 ->
+    BN -> ReLU -> conv3x3 d=2 -> BN -> ReLU -> conv3x3 d=3 -> BN; out = relu(main + shortcut)."""
+    conv = lambda t, p, d: F.conv2d(t, state[prefix + p + ".weight"], state[prefix + p + ".bias"], padding=d, dilation=d)
+    re = _bn(F.conv2d(x, state[prefix + ".c1.0.weight"], state[prefix + ".c1.0.bias"]), state, prefix + ".c1.1",
+             training, update_stats)
+    y = torch.relu(_bn(conv(x, ".cbr1.0", 1), state, prefix + ".cbr1.1", training, update_stats))
+    y = torch.relu(_bn(conv(y, ".cbr2.0", 2), state, prefix + ".cbr2.1", training, update_stats))
+    y = _bn(conv(y, ".cbr3.0", 3), state, prefix + ".cbr3.1", training, update_stats)
+    return torch.relu(y + re)
+
+
+def mdam(x, state, prefix, group=32):
+    """MDAM.forward — attention.py:171-190, step by step: channels split into `group` groups of
+    cg; strip pooling over W and over H -> shared 1x1 conv -> sigmoid gates; GroupNorm (cg groups
+    of one channel) of the gated map -> global average -> softmax over the cg channels; squeeze
+    path conv3x3 -> global average -> 1x1 -> ReLU -> 1x1 -> sigmoid; out = x * sigmoid(sum)."""
+    b, c, h, w = x.shape
+    cg = c // group
+    gx = x.reshape(b * group, cg, h, w)
+    x_h = gx.mean(dim=3, keepdim=True)                                   # [bg, cg, h, 1]
+    x_w = gx.mean(dim=2, keepdim=True).permute(0, 1, 3, 2)               # [bg, cg, w, 1]
+    hw = F.conv2d(torch.cat([x_h, x_w], dim=2), state[prefix + ".conv1x1.weight"], state[prefix + ".conv1x1.bias"])
+    x_h, x_w = torch.split(hw, [h, w], dim=2)
+    gated = gx * torch.sigmoid(x_h) * torch.sigmoid(x_w.permute(0, 1, 3, 2))
+    gn = F.group_norm(gated, cg, state[prefix + ".groupNorm.weight"], state[prefix + ".groupNorm.bias"], eps=1e-5)
+    a = torch.softmax(gn.mean(dim=(2, 3), keepdim=True), dim=1)
+    y = F.conv2d(gx, state[prefix + ".conv3x3.weight"], state[prefix + ".conv3x3.bias"], padding=1)
+    y = y.mean(dim=(2, 3), keepdim=True)
+    y = torch.sigmoid(F.conv2d(torch.relu(F.conv2d(y, state[prefix + ".fc.0.weight"])), state[prefix + ".fc.2.weight"]))
+    return (gx * torch.sigmoid(a + y)).reshape(b, c, h, w)
+
+
+def rdam_unet_forward(x, state, training=True, update_stats=True):
+    """RDAM_UNet.forward with every Dropout2d at p=0 — model/rdam_unet.py:63-115."""
+    rd = lambda t, name: res_dconv(t, state, name, training, update_stats)
+    ac = lambda t, name: amsfn(t, state, name, training, update_stats)
+    at = lambda t, name: mdam(t, state, name)
+    e1 = F.conv2d(x, state["encoder1.weight"], state["encoder1.bias"], padding=1)
+    m1 = at(e1, "att1")
+    e2 = rd(maxpool2x2(ac(e1, "acpn0")), "encoder2")
+    m2 = at(e2, "att2")
+    e3 = rd(maxpool2x2(ac(e2, "acpn1")), "encoder3")
+    m3 = at(e3, "att3")
+    e4 = rd(maxpool2x2(ac(e3, "acpn2")), "encoder4")
+    m4 = at(e4, "att4")
+    c5 = double_conv(maxpool2x2(ac(e4, "acpn3")), state, "center_conv", training, update_stats)
+    d = ac(rd(torch.cat([upsample2x_bilinear(c5), m4], dim=1), "decoder1"), "acpn5")
+    d = ac(rd(torch.cat([upsample2x_bilinear(d), m3], dim=1), "decoder2"), "acpn6")
+    d = ac(rd(torch.cat([upsample2x_bilinear(d), m2], dim=1), "decoder3"), "acpn7")
+    d1 = F.conv2d(torch.cat([upsample2x_bilinear(d), m1], dim=1), state["decoder4.weight"], state["decoder4.bias"],
+                  padding=1)
+    return double_conv(ac(d1, "acpn8"), state, "out_conv", training, update_stats)
+
+
 PARAM_SUFFIXES = (".0.weight", ".0.bias", ".1.weight", ".1.bias")
 
 

@@ -65,13 +65,17 @@ def import_reference(ref_root):
     # the same mis-indented `if m.bias` ends DWConv's and AMSFN's initialisers (modules.py:76, 884)
     M.DWConv._initialize_weights = lambda self, init_gain=0.02: None
     M.AMSFN._initialize_weights = lambda self, init_gain=0.02: None
+    M.ResDConv._initialize_weights = lambda self, init_gain=0.02: None      # same defect, modules.py:470
+    from model.utils import attention as A
     from model.unet import UNet
     from model.a_unet import A_UNet
+    from model.rdam_unet import RDAM_UNet
     from utils.loss_fn import diceloss, Focal_Loss, IOULoss
     from utils.metrics import Metrics
     from utils.train_and_eval import train_one_epoch, evaluate
     from utils.slide_predict import SlidingWindowPredictor
     return types.SimpleNamespace(DoubleConv=M.DoubleConv, UNet=UNet, A_UNet=A_UNet, AMSFN=M.AMSFN, diceloss=diceloss,
+                                 RDAM_UNet=RDAM_UNet, ResDConv=M.ResDConv, MDAM=A.MDAM,
                                  Focal_Loss=Focal_Loss, IOULoss=IOULoss, Metrics=Metrics,
                                  train_one_epoch=train_one_epoch, evaluate=evaluate,
                                  SlidingWindowPredictor=SlidingWindowPredictor)
@@ -426,6 +430,76 @@ def gold_a_unet(R, out):
         out[f"amsfn.grad.{k}"] = p.grad.numpy()
 
 
+def rdam_cases():
+    return {"rdam_a": dict(B=2, cin=3, ncls=4, base=32, hw=32, seed=61)}
+
+
+def rdam_block_cases():
+    """stand-alone blocks: (kind, constructor args, input shape, seed)"""
+    return {"resd_a": ("resd", (32, 64), (2, 32, 20, 12), 71), "resd_b": ("resd", (64, 32), (1, 64, 9, 17), 72),
+            "mdam_a": ("mdam", (32,), (2, 32, 12, 20), 73), "mdam_b": ("mdam", (128,), (1, 128, 7, 5), 74)}
+
+
+def _block_fixture(blk, shape, seed, name, out, positive_input):
+    spec = [(k, tuple(v.shape)) for k, v in blk.state_dict().items()]
+    st = orc.hash_state(spec, seed)
+    blk.load_state_dict({k: v.clone() for k, v in st.items()})
+    blk.train()
+    x = dg.hash_normalish(shape, seed + 100)
+    x = T(np.maximum(x, 0) if positive_input else x).requires_grad_(True)
+    gy = T(dg.hash_normalish(shape[:1] + (blk_out_channels(blk, shape),) + shape[2:], seed + 200))
+    y = blk(x)
+    y.backward(gy)
+    out[f"{name}.keys"] = np.array([k for k, _ in spec])
+    out[f"{name}.shapes"] = np.array([",".join(map(str, s)) for _, s in spec])
+    out[f"{name}.y"] = y.detach().numpy()
+    out[f"{name}.dx"] = x.grad.numpy()
+    for k, p in blk.named_parameters():
+        out[f"{name}.grad.{k}"] = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+    for k, b in blk.named_buffers():
+        out[f"{name}.buf.{k}"] = b.detach().numpy().copy()
+
+
+def blk_out_channels(blk, shape):
+    return blk.c1[0].out_channels if hasattr(blk, "c1") else shape[1]
+
+
+def gold_rdam(R, out):
+    """RDAM_UNet (model/rdam_unet.py) and its two new blocks on their own (ResDConv with input
+    and parameter gradients and updated running statistics; MDAM likewise): parameters from the
+    hash generator in state_dict order, train-mode forward + backward."""
+    for name, (kind, args, shape, seed) in rdam_block_cases().items():
+        blk = R.ResDConv(*args) if kind == "resd" else R.MDAM(*args)
+        _block_fixture(blk, shape, seed, name, out, positive_input=(kind == "resd"))
+    for name, c in rdam_cases().items():
+        m = R.RDAM_UNet(c["cin"], c["ncls"], 0, base_channels=c["base"])
+        spec = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        st = orc.hash_state(spec, c["seed"])
+        m.load_state_dict({k: v.clone() for k, v in st.items()})
+        m.train()
+        x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100))
+        t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+        names = [f"c{i}" for i in range(1, c["ncls"])]
+        logits = m(x)
+        ld = R.diceloss(names)(logits, t)
+        ld["total_loss"].backward()
+        out[f"{name}.keys"] = np.array([k for k, _ in spec])
+        out[f"{name}.shapes"] = np.array([",".join(map(str, s)) for _, s in spec])
+        out[f"{name}.logits"] = logits.detach().numpy()
+        out[f"{name}.loss"] = np.array([float(v) for v in ld.values()], dtype=np.float64)
+        params = dict(m.named_parameters())
+        out[f"{name}.grad_keys"] = np.array(list(params.keys()))
+        out[f"{name}.grad_norms"] = np.array([float(p.grad.double().norm()) if p.grad is not None else 0.0
+                                              for p in params.values()])
+        out[f"{name}.grad_samples"] = np.stack([
+            (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().reshape(-1)[sample_idx(p.numel())]
+            for p in params.values()])
+        out[f"{name}.running_mean.encoder3.cbr3"] = m.encoder3.cbr3[1].running_mean.numpy().copy()
+        m.eval()
+        with torch.no_grad():
+            out[f"{name}.eval_logits"] = m(x).numpy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -436,7 +510,7 @@ def main():
     R = import_reference(args.ref)
     groups = {"double_conv": gold_double_conv, "unet": gold_unet, "pool_up": gold_pool_up,
               "loss": gold_loss, "metrics": gold_metrics, "train": gold_train, "dp": gold_dp,
-              "slide": gold_slide, "a_unet": gold_a_unet}
+              "slide": gold_slide, "a_unet": gold_a_unet, "rdam": gold_rdam}
     only = [g for g in args.only.split(",") if g]
     for gname, fn in groups.items():
         if only and gname not in only:

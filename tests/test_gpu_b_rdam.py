@@ -1,0 +1,171 @@
+"""GPU suite: RDAM_UNet (model/rdam_unet.py of the reference) and its two blocks — ResDConv
+(dilated 3x3 convs + 1x1 shortcut, modules.py:426-453) and MDAM (attention.py:147-190) — through the
+HIP path against the golden vectors the reference itself produced (tests/golden/rdam.npz), plus the
+dilated conv kernels against torch's conv on the CPU.
+
+float32 mode: block outputs 1e-4 of their scale (MDAM 1e-5), input gradients 1e-3, parameter
+gradients 2e-3 of each tensor's scale; whole network: logits 1e-3 of their scale, losses 1e-5,
+gradient norms 5 %.  bfloat16 mode: loss within 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from oracle import datagen as dg
+from oracle import unet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else T(np.asarray(b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def state_from_golden(g, name, seed):
+    spec = [(str(k), tuple(int(v) for v in str(s).split(",") if v)) for k, s in zip(g[f"{name}.keys"], g[f"{name}.shapes"])]
+    return orc.hash_state(spec, seed)
+
+
+def act(a, dtype=torch.float32):
+    t = a if torch.is_tensor(a) else T(a)
+    return t.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dil", [2, 3])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 20, 12), (1, 32, 128, 9, 37), (1, 64, 32, 16, 16), (2, 8, 24, 5, 5),
+                                   (1, 256, 128, 8, 8)])
+@pytest.mark.parametrize("lazy", [False, True])
+def test_dilated_conv_kernels(dtype, dil, shape, lazy):
+    """mis_conv3x3_dilated_fwd (forward and, on the transposed image, data gradient) and
+    mis_conv3x3_dilated_wgrad against torch's dilated conv in float64 on the same (dtype-rounded) values."""
+    from medical_image_segmentation_amd import functional as F_
+    B, Ci, Co, H, W = shape
+    if not F_.query("mis_conv3x3_dilated_supported", F_._DT[dtype], B, H, W, Ci, Co, dil):
+        pytest.skip("shape not taken by the matrix-core kernels in this dtype")
+    q = lambda a: T(a).to(dtype).double()
+    x = dg.hash_normalish((B, Ci, H, W), 2101)
+    w = dg.hash_normalish((Co, Ci, 3, 3), 2102, std=(2.0 / (9 * Co)) ** 0.5)
+    b = dg.hash_uniform((Co,), 2103, -0.1, 0.1)
+    gz = dg.hash_normalish((B, Co, H, W), 2104)
+    ss = None
+    xv = q(x)
+    if lazy:
+        sc = dg.hash_uniform((Ci,), 2105, 0.4, 1.6) * np.where(dg.hash_uniform((Ci,), 2106, 0, 1) < 0.25, -1.0, 1.0)
+        ss = T(np.stack([sc, dg.hash_uniform((Ci,), 2107, -0.5, 0.5)]).astype(np.float32))
+        xv = torch.relu(q(x) * ss[0].double()[None, :, None, None] + ss[1].double()[None, :, None, None]).float()
+        xv = xv.to(dtype).double()
+    wd_, bd_ = T(w).to(DEV), T(b).to(DEV)
+    xd = act(x, dtype)
+    ssd = ss.to(DEV) if lazy else None
+    wf, wt = F_.pack_weights_pair(wd_, dtype)
+    z, _ = F_.conv3x3_raw(xd, wf, bd_, Co, False, ssd, dilation=dil)
+    wo = q(w) if dtype == torch.bfloat16 else T(w).double()
+    zo = torch.nn.functional.conv2d(xv, wo, T(b).double(), padding=dil, dilation=dil)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(z, zo) < tol
+    # data gradient: the same kernel on the transposed weight image
+    gzd = act(gz, dtype)
+    dx, _ = F_.conv3x3_raw(gzd, wt, None, Ci, False, dilation=dil)
+    dxo = torch.nn.grad.conv2d_input((B, Ci, H, W), wo, q(gz), padding=dil, dilation=dil)
+    assert rel_err(dx, dxo) < tol
+    dw = F_.conv3x3_wgrad_raw(xd, gzd, ssd, dilation=dil)
+    dwo = torch.nn.grad.conv2d_weight(xv, (Co, Ci, 3, 3), q(gz), padding=dil, dilation=dil)
+    assert rel_err(dw, dwo) < (2e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("name", list(mg.rdam_block_cases()))
+def test_rdam_blocks_golden(golden, name):
+    from medical_image_segmentation_amd.model.utils.attention import MDAM
+    from medical_image_segmentation_amd.model.utils.modules import ResDConv
+    g = golden("rdam")
+    kind, args, shape, seed = mg.rdam_block_cases()[name]
+    st = state_from_golden(g, name, seed)
+    blk = ResDConv(*args) if kind == "resd" else MDAM(*args)
+    assert list(blk.state_dict().keys()) == list(st.keys())
+    blk.load_state_dict(st)
+    blk = blk.to(DEV).train()
+    x = dg.hash_normalish(shape, seed + 100)
+    x = act(np.maximum(x, 0) if kind == "resd" else x).requires_grad_(True)
+    y = blk(x)
+    gy = act(dg.hash_normalish(tuple(y.shape), seed + 200))
+    y.backward(gy)
+    assert rel_err(y, g[f"{name}.y"]) < (1e-4 if kind == "resd" else 1e-5)
+    assert rel_err(x.grad, g[f"{name}.dx"]) < 1e-3
+    scale = max(float(np.abs(g[f"{name}.grad.{k}"]).max()) for k, _ in blk.named_parameters())
+    for k, p in blk.named_parameters():
+        ref = g[f"{name}.grad.{k}"]
+        if (kind == "resd" and k.endswith(".0.bias")) or k in ("conv1x1.weight", "conv1x1.bias", "groupNorm.weight"):
+            # analytically zero (conv bias in front of a train-mode BatchNorm; MDAM's strip-pooling
+            # branch, whose GroupNorm -> global average is the GroupNorm bias): round-off in the fixture
+            assert float(p.grad.abs().max()) < 1e-4 * scale and float(np.abs(ref).max()) < 1e-4 * scale, k
+            continue
+        assert float((p.grad.double().cpu() - T(ref).double()).abs().max()) < 2e-3 * max(float(np.abs(ref).max()),
+                                                                                        1e-2 * scale), k
+    for k, b_ in blk.named_buffers():
+        assert rel_err(b_.float(), g[f"{name}.buf.{k}"]) < 1e-4, k
+
+
+@pytest.mark.parametrize("name", list(mg.rdam_cases()))
+def test_rdam_unet_fp32_golden(golden, report, name):
+    from medical_image_segmentation_amd.model.rdam_unet import RDAM_UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    g = golden("rdam")
+    c = mg.rdam_cases()[name]
+    st = state_from_golden(g, name, c["seed"])
+    m = RDAM_UNet(c["cin"], c["ncls"], 0, base_channels=c["base"], compute_dtype=torch.float32)
+    assert list(m.state_dict().keys()) == list(st.keys())
+    m.load_state_dict(st)
+    m = m.to(DEV).train()
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(DEV)
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)).to(DEV)
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    logits = m(x)
+    ld = diceloss(names)(logits, t)
+    ld["total_loss"].backward()
+    report("fp32 logits max error / max |logit|", rel_err(logits, g[f"{name}.logits"]))
+    assert rel_err(logits, g[f"{name}.logits"]) < 1e-3
+    np.testing.assert_allclose([float(v.detach()) for v in ld.values()], g[f"{name}.loss"], rtol=1e-5, atol=1e-5)
+    params = dict(m.named_parameters())
+    keys = [str(k) for k in g[f"{name}.grad_keys"]]
+    assert keys == list(params.keys())
+    assert all(p.grad is not None for p in params.values())
+    norms = np.array([float(params[k].grad.double().norm()) for k in keys])
+    ref = g[f"{name}.grad_norms"]
+    big = ref > 1e-3 * ref.max()
+    dev = float(np.abs(norms[big] - ref[big]).max() / ref.max())
+    report("fp32 gradient norm deviation / largest norm", dev)
+    assert dev < 5e-2
+    assert rel_err(m.encoder3.cbr3[1].running_mean, g[f"{name}.running_mean.encoder3.cbr3"]) < 1e-3
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(x), g[f"{name}.eval_logits"]) < 1e-3
+
+
+def test_rdam_unet_bf16_and_dropout(golden, report):
+    from medical_image_segmentation_amd.model.rdam_unet import RDAM_UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    g = golden("rdam")
+    name = "rdam_a"
+    c = mg.rdam_cases()[name]
+    st = state_from_golden(g, name, c["seed"])
+    m = RDAM_UNet(c["cin"], c["ncls"], 0, base_channels=c["base"], compute_dtype=torch.bfloat16)
+    m.load_state_dict(st)
+    m = m.to(DEV).train()
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(DEV)
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)).to(DEV)
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    logits = m(x)
+    assert logits.dtype == torch.bfloat16
+    ld = diceloss(names)(logits, t)
+    ld["total_loss"].backward()
+    report("bf16 total loss difference vs fp32 reference", abs(float(ld["total_loss"].detach()) - g[f"{name}.loss"][-1]))
+    assert abs(float(ld["total_loss"].detach()) - g[f"{name}.loss"][-1]) < 2e-2
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    m2 = RDAM_UNet(c["cin"], c["ncls"], 0.5, base_channels=c["base"], compute_dtype=torch.float32).to(DEV).train()
+    y = m2(x)
+    assert torch.isfinite(y).all()

@@ -315,3 +315,59 @@ def test_a_unet(golden, name):
     with torch.no_grad():
         ev = orc.a_unet_forward(x, st, training=False).numpy()
         assert float(np.abs(ev - g[f"{name}.eval_logits"]).max()) < 1e-3 * float(np.abs(g[f"{name}.eval_logits"]).max())
+
+
+def _state_from_golden(g, name, seed, dtype=torch.float64):
+    spec = [(str(k), tuple(int(v) for v in str(s).split(",") if v)) for k, s in zip(g[f"{name}.keys"], g[f"{name}.shapes"])]
+    return orc.hash_state(spec, seed, dtype=dtype)
+
+
+@pytest.mark.parametrize("name", list(mg.rdam_block_cases()))
+def test_rdam_blocks(golden, name):
+    """ResDConv and MDAM restatements against the reference's own outputs and gradients."""
+    g = golden("rdam")
+    kind, args, shape, seed = mg.rdam_block_cases()[name]
+    st = _state_from_golden(g, name, seed)
+    pk = [k for k in st if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    for k in pk:
+        st[k].requires_grad_(True)
+    x = dg.hash_normalish(shape, seed + 100)
+    x = T(np.maximum(x, 0) if kind == "resd" else x).double().requires_grad_(True)
+    st2 = {"blk." + k: v for k, v in st.items()}
+    y = orc.res_dconv(x, st2, "blk") if kind == "resd" else orc.mdam(x, st2, "blk")
+    gy = T(dg.hash_normalish(tuple(y.shape), seed + 200)).double()
+    y.backward(gy)
+    close(y.detach().numpy(), g[f"{name}.y"], 1e-5, 1e-5)
+    # (the fixture is the reference's float32 run: its input gradient, three BatchNorm backwards deep,
+    # carries ~1e-4 of its scale in round-off)
+    assert np.abs(x.grad.numpy() - g[f"{name}.dx"]).max() < 5e-4 * np.abs(g[f"{name}.dx"]).max()
+    scale = max(float(np.abs(g[f"{name}.grad.{k}"]).max()) for k in pk)
+    for k in pk:
+        ref = g[f"{name}.grad.{k}"]
+        got = st[k].grad.numpy() if st[k].grad is not None else np.zeros_like(ref)
+        if kind == "resd" and k.endswith(".0.bias"):
+            # conv bias in front of a train-mode BatchNorm: analytically zero, float32 round-off in the fixture
+            assert np.abs(ref).max() < 1e-4 * scale and np.abs(got).max() < 1e-9 * scale, k
+            continue
+        assert np.abs(got - ref).max() < 5e-4 * max(np.abs(ref).max(), 1e-3 * scale) + 1e-7, k
+    if kind == "mdam":
+        # the strip-pooling branch ends in GroupNorm -> global average = the GroupNorm bias: its
+        # parameters get round-off-sized gradients in the reference (the HIP path relies on that)
+        for k in ("conv1x1.weight", "conv1x1.bias", "groupNorm.weight"):
+            assert np.abs(g[f"{name}.grad.{k}"]).max() < 1e-5 * scale, k
+
+
+@pytest.mark.parametrize("name", list(mg.rdam_cases()))
+def test_rdam_unet(golden, name):
+    g = golden("rdam")
+    c = mg.rdam_cases()[name]
+    st = _state_from_golden(g, name, c["seed"])
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).double()
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+    logits = orc.rdam_unet_forward(x, st)
+    rel = lambda a, b: float(np.abs(np.asarray(a) - b).max() / np.abs(b).max())
+    assert rel(logits.numpy(), g[f"{name}.logits"]) < 1e-3         # float32 reference, ~100 layers deep
+    ld = orc.dice_loss(logits, t, [f"c{i}" for i in range(1, c["ncls"])])
+    close([float(v) for v in ld.values()], g[f"{name}.loss"], 1e-5, 1e-6)
+    close(st["encoder3.cbr3.1.running_mean"].numpy(), g[f"{name}.running_mean.encoder3.cbr3"], 1e-4, 1e-6)
+    assert rel(orc.rdam_unet_forward(x, st, training=False).numpy(), g[f"{name}.eval_logits"]) < 1e-3
