@@ -31,8 +31,28 @@
 #ifndef MIS_DBG
 #define MIS_DBG 0
 #endif
+// -DMIS_TIMELINE=1 (tuning builds only): wave 0 of a few workgroups of the forward kernel writes
+// a cycle-counter stamp at every phase boundary; mis_debug_timeline() copies the stamps out.
+#ifndef MIS_TIMELINE
+#define MIS_TIMELINE 0
+#endif
 
 namespace {
+
+#if MIS_TIMELINE
+__device__ unsigned long long mis_tl_buf[4][1024];
+#define TL_STAMP(ID)                                                                                     \
+  {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (tl_slot >= 0 && tl_n < 1022)                                                                     \
+      mis_tl_buf[tl_slot][tl_n++] = ((unsigned long long)(ID) << 56) | ((unsigned long long)clock64() & 0x00FFFFFFFFFFFFFFull); \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+#define TL_WAIT_LOADS() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TL_STAMP(16) }
+#else
+#define TL_STAMP(ID)
+#define TL_WAIT_LOADS()
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // Output tile: 4 waves x MT 16-pixel row segments each, arranged as MX segments side by side
@@ -43,6 +63,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #endif
 #ifndef MIS_DEEP
 #define MIS_DEEP 1
+#endif
+#ifndef MIS_AFF_REGS
+#define MIS_AFF_REGS 1
 #endif
 #ifndef MIS_PRE_REL
 #define MIS_PRE_REL 0
@@ -80,6 +103,16 @@ constexpr int nsteps_of(int cpg) { return (9 * cpg + 3) / 4; }
 template <typename T>
 __device__ __forceinline__ u32x4 affine_relu_raw(u32x4 raw, const float* sc, const float* sh) {
   constexpr int G = 16 / (int)sizeof(T);
+  union { u32x4 u; T t[G]; } v;
+  v.u = raw;
+#pragma unroll
+  for (int k = 0; k < G; k++) v.t[k] = from_f32<T>(fmaxf(to_f32(v.t[k]) * sc[k] + sh[k], 0.f));
+  return v.u;
+}
+
+// The same with the vector's scale and shift already in registers.
+template <typename T, int G>
+__device__ __forceinline__ u32x4 affine_relu_regs(u32x4 raw, const float (&sc)[G], const float (&sh)[G]) {
   union { u32x4 u; T t[G]; } v;
   v.u = raw;
 #pragma unroll
@@ -252,6 +285,12 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kg = lane >> 4;
   const int n0 = blockIdx.y * NT;                 // first n-tile of this workgroup
+#if MIS_TIMELINE
+  int tl_n = 0;
+  const int tl_slot = (tid != 0 || blockIdx.y != 0) ? -1
+                      : blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : blockIdx.x == gridDim.x - 1 ? 2 : -1;
+  TL_STAMP(1)
+#endif
 
   // per-lane tap offsets of each MFMA step (positions inside the halo) and channel group
   // (with 4 groups per position a step is exactly one tap: offsets are compile-time constants)
@@ -325,6 +364,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   // requested while tile t computes, so a load has two tile times to arrive.  Measured on the
   // write-heavy layers: reads queued behind a saturated store path otherwise stall the pipeline
   // (time = read phase + write phase instead of their maximum).
+  constexpr bool AFF_REGS = (CM_THREADS % CPG == 0) && (MIS_AFF_REGS != 0);
   constexpr bool DEEP = (CPG < 4) && (MIS_DEEP != 0) && !BNS && DIL == 1;   // (the fused-sums epilogue twice over would spill)
   u32x4 hreg[HALO_IT], hregB[DEEP ? HALO_IT : 1], wreg[W_IT];
 #define HREG hreg
@@ -357,17 +397,45 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   // ReLU of the producing layer are applied here, to in-image positions only (padding stays 0).
 #define STORE_HALO(P, CHUNK)                                                                             \
   {                                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                                \
-      u32x4 val = HREG[i];                                                                               \
-      if (((CHUNK) >= n_chunks_a) ? (affb != nullptr) : (affa != nullptr)) {                             \
-        const int v = tid + i * CM_THREADS;                                                              \
-        const int pos = v / CPG, cg = v % CPG;                                                           \
-        const int gy = (P).ty * TH - DIL + pos / HW_, gx = (P).tx * TW - DIL + pos % HW_;                \
-        const int c = (CHUNK) * KC + cg * G;                                                             \
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)                                    \
-          val = affine_relu_raw<T>(val, aff + c, aff + Cin + c);                                         \
+    const bool lazy_ = ((CHUNK) >= n_chunks_a) ? (affb != nullptr) : (affa != nullptr);                  \
+    if (AFF_REGS && lazy_) {                                                                             \
+      /* every element of a thread has the same channel group (the workgroup size is a multiple of */    \
+      /* CPG): its scale and shift are fetched once per stage, ahead of the wait for the halo loads, */  \
+      /* and the in-image test is a select, so the elements form no chain of LDS round trips */          \
+      const int c_ = (CHUNK) * KC + (tid % CPG) * G;                                                     \
+      float sc_[G], sh_[G];                                                                              \
+      _Pragma("unroll") for (int k = 0; k < G; k += 4) {                                                 \
+        const f32x4 a_ = *reinterpret_cast<const f32x4*>(aff + c_ + k);                                  \
+        const f32x4 b_ = *reinterpret_cast<const f32x4*>(aff + Cin + c_ + k);                            \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                  \
+          sc_[k + r] = a_[r];                                                                            \
+          sh_[k + r] = b_[r];                                                                            \
+        }                                                                                                \
       }                                                                                                  \
-      *reinterpret_cast<u32x4*>(halo + (PRE ? h_lds[PRE ? i : 0] : halo_lds(i))) = val;                  \
+      const int gy0_ = (P).ty * TH - DIL, gx0_ = (P).tx * TW - DIL;                                      \
+      _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                              \
+        const u32x4 raw_ = HREG[i];                                                                      \
+        const unsigned pos = ((unsigned)tid + i * CM_THREADS) / CPG;                                     \
+        const bool in_ = (unsigned)(gy0_ + (int)(pos / HW_)) < (unsigned)H &&                            \
+                         (unsigned)(gx0_ + (int)(pos % HW_)) < (unsigned)W;                              \
+        const u32x4 act_ = affine_relu_regs<T, G>(raw_, sc_, sh_);                                       \
+        u32x4 val;                                                                                       \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) val[r] = in_ ? act_[r] : raw_[r];                  \
+        *reinterpret_cast<u32x4*>(halo + (PRE ? h_lds[PRE ? i : 0] : halo_lds(i))) = val;                \
+      }                                                                                                  \
+    } else {                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < HALO_IT; i++) {                                              \
+        u32x4 val = HREG[i];                                                                             \
+        if (lazy_) {                                                                                     \
+          const int v = tid + i * CM_THREADS;                                                            \
+          const int pos = v / CPG, cg = v % CPG;                                                         \
+          const int gy = (P).ty * TH - DIL + pos / HW_, gx = (P).tx * TW - DIL + pos % HW_;              \
+          const int c = (CHUNK) * KC + cg * G;                                                           \
+          if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)                                  \
+            val = affine_relu_raw<T>(val, aff + c, aff + Cin + c);                                       \
+        }                                                                                                \
+        *reinterpret_cast<u32x4*>(halo + (PRE ? h_lds[PRE ? i : 0] : halo_lds(i))) = val;                \
+      }                                                                                                  \
     }                                                                                                    \
   }
 #define LOAD_W(CHUNK, LIVE)                                                                              \
@@ -566,15 +634,20 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   // read out of range = zeros).  FIRST_CHUNK: the accumulators start from the bias.
 #define STAGE(CHUNK, FIRST_CHUNK)                                                                        \
   {                                                                                                      \
+    TL_STAMP(10)                                                                                         \
     if (live) {                                                                                          \
       __syncthreads(); /* every wave is done reading the previous stage */                               \
+      TL_STAMP(11)                                                                                       \
+      TL_WAIT_LOADS()                                                                                    \
       if constexpr (!PRE) asm volatile("" : "+v"(tid_l));                                                \
       STORE_HALO(cur, (CHUNK))                                                                           \
       if constexpr (!W_ONCE) {                                                                           \
         if (!w_resident || first) STORE_W()                                                              \
         first = false;                                                                                   \
       }                                                                                                  \
+      TL_STAMP(12)                                                                                       \
       __syncthreads();                                                                                   \
+      TL_STAMP(13)                                                                                       \
     }                                                                                                    \
     if constexpr (!PRE) asm volatile("" : "+v"(tid_l));                                                  \
     if ((CHUNK) + 1 < nch) {                                                                             \
@@ -585,7 +658,9 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
       if constexpr (!W_ONCE) LOAD_W(0, (!w_resident || !live) && it + 1 < t_count)                       \
     }                                                                                                    \
     __builtin_amdgcn_sched_barrier(0); /* loads stay ahead of the MFMAs (the scheduler would sink them) */ \
+    TL_STAMP(14)                                                                                         \
     STAGE_MFMA(FIRST_CHUNK)                                                                              \
+    TL_STAMP(15)                                                                                         \
   }
 
   // The loop runs one extra, leading iteration (it = -1) that only issues the first tile's
@@ -594,6 +669,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   // an epilogue's stores — and the wait the compiler derives covers the loads only: a tile
   // does not wait for the previous tile's stores to be acknowledged (the counter retires in
   // order and the stores are younger than the loads).
+  TL_STAMP(2)
   TilePos nxt = cur;
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -608,15 +684,23 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   {                                                                                                      \
     const int idx_ = (IDX);                                                                              \
     const bool live = idx_ >= 0 && idx_ < t_count;                                                       \
+    TL_STAMP(10)                                                                                         \
     if (live) {                                                                                          \
       __syncthreads();                                                                                   \
+      TL_STAMP(11)                                                                                       \
+      TL_WAIT_LOADS()                                                                                    \
       STORE_HALO(cur, 0)                                                                                 \
+      TL_STAMP(12)                                                                                       \
       __syncthreads();                                                                                   \
+      TL_STAMP(13)                                                                                       \
     }                                                                                                    \
     LOAD_HALO(nxt, 0, idx_ + 2 < t_count)                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
+    TL_STAMP(14)                                                                                         \
     STAGE_MFMA(true)                                                                                     \
+    TL_STAMP(15)                                                                                         \
     EPILOGUE()                                                                                           \
+    TL_STAMP(20)                                                                                         \
     if (live) cur.next(tiles_x, tiles_y);                                                                \
     nxt.next(tiles_x, tiles_y);                                                                          \
   }
@@ -638,6 +722,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
       STAGE(0, true)
       for (int chunk = 1; chunk < nch; chunk++) STAGE(chunk, false)
       EPILOGUE()
+      TL_STAMP(20)
       cur = nxt;
     }
   }
@@ -666,6 +751,10 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
       if (co < Cout) partials[((int64_t)blockIdx.x * 2 + which) * Cout + co] = v;
     }
   }
+#if MIS_TIMELINE
+  TL_STAMP(30)
+  if (tl_slot >= 0) mis_tl_buf[tl_slot][1023] = (unsigned long long)tl_n;
+#endif
 }
 
 #undef LOAD_HALO
@@ -1089,6 +1178,8 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   }
 
   u32x4 xr[XIT], zr[ZIT];
+  // (the variants at their register limit would spill the 16 extra values: they keep the per-element form)
+  constexpr bool WG_AFF_REGS = (NTHR % XVP == 0) && (MIS_AFF_REGS != 0) && !(NTI == 2 && (WK == 4 || WCO == 2));
   const int ximg_bytes = H * W * Csrc * (int)sizeof(T), zimg_bytes = H * W * Cout * (int)sizeof(T);
   // a dead stage (past the last tile) shifts x far left: nothing loads
 #define WG_LOAD(P, LIVE)                                                                                \
@@ -1112,15 +1203,41 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   }
 #define WG_STORE(P)                                                                                     \
   {                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                   \
-      u32x4 val = xr[i];                                                                                \
-      if (x_aff) {                                                                                      \
-        const int v = tid + i * NTHR, pos = v / XVP, cv = v % XVP;                                      \
-        const int gy = (P).ty * TH - DIL + pos / HWW, gx = (P).tx * WG_TW - DIL + pos % HWW;            \
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && cl0 + cv * G < Csrc)            \
-          val = affine_relu_raw<T>(val, aff + cv * G, aff + CTI + cv * G);                              \
+    if (WG_AFF_REGS && x_aff) {                                                                         \
+      /* a thread's elements all have the same channel vector (NTHR is a multiple of XVP): scale and */ \
+      /* shift are read once per stage, the in-image test is a select (no per-element LDS round trip) */ \
+      const int cv_ = tid % XVP;                                                                        \
+      float sc_[G], sh_[G];                                                                             \
+      _Pragma("unroll") for (int k = 0; k < G; k += 4) {                                                \
+        const f32x4 a_ = *reinterpret_cast<const f32x4*>(aff + cv_ * G + k);                            \
+        const f32x4 b_ = *reinterpret_cast<const f32x4*>(aff + CTI + cv_ * G + k);                      \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                 \
+          sc_[k + r] = a_[r];                                                                           \
+          sh_[k + r] = b_[r];                                                                           \
+        }                                                                                               \
       }                                                                                                 \
-      *reinterpret_cast<u32x4*>(xh + x_lds[i]) = val;                                                   \
+      const int gy0_ = (P).ty * TH - DIL, gx0_ = (P).tx * WG_TW - DIL;                                  \
+      _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                 \
+        const u32x4 raw_ = xr[i];                                                                       \
+        const unsigned pos = ((unsigned)tid + i * NTHR) / XVP;                                          \
+        const bool in_ = (unsigned)(gy0_ + (int)(pos / HWW)) < (unsigned)H &&                           \
+                         (unsigned)(gx0_ + (int)(pos % HWW)) < (unsigned)W;                             \
+        const u32x4 act_ = affine_relu_regs<T, G>(raw_, sc_, sh_);                                      \
+        u32x4 val;                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) val[r] = in_ ? act_[r] : raw_[r];                 \
+        *reinterpret_cast<u32x4*>(xh + x_lds[i]) = val;                                                 \
+      }                                                                                                 \
+    } else {                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                 \
+        u32x4 val = xr[i];                                                                              \
+        if (x_aff) {                                                                                    \
+          const int v = tid + i * NTHR, pos = v / XVP, cv = v % XVP;                                    \
+          const int gy = (P).ty * TH - DIL + pos / HWW, gx = (P).tx * WG_TW - DIL + pos % HWW;          \
+          if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && cl0 + cv * G < Csrc)          \
+            val = affine_relu_raw<T>(val, aff + cv * G, aff + CTI + cv * G);                            \
+        }                                                                                               \
+        *reinterpret_cast<u32x4*>(xh + x_lds[i]) = val;                                                 \
+      }                                                                                                 \
     }                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < ZIT; i++) *reinterpret_cast<u32x4*>(zt + z_lds[i]) = zr[i];   \
   }
@@ -1412,3 +1529,9 @@ int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H
   if (dtype == MIS_BF16) return run_wgrad<bf16>(in, dz, B, H, W, Cout, dw, bias, workspace, st, dil);
   return run_wgrad<float>(in, dz, B, H, W, Cout, dw, bias, workspace, st, dil);
 }
+
+#if MIS_TIMELINE
+extern "C" int mis_debug_timeline(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mis_tl_buf), sizeof(mis_tl_buf));
+}
+#endif
