@@ -64,6 +64,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #ifndef MIS_DEEP
 #define MIS_DEEP 1
 #endif
+#ifndef MIS_PIN_FRAGS
+#define MIS_PIN_FRAGS 0
+#endif
+#ifndef MIS_WS_FRAG2
+#define MIS_WS_FRAG2 1
+#endif
 #ifndef MIS_AFF_REGS
 #define MIS_AFF_REGS 1
 #endif
@@ -244,8 +250,16 @@ constexpr int fwd_min_blocks(int nt, int cpg) { return (nt == 4 || nt * cpg >= 6
 
 // DIL: dilation of the 3x3 taps (padding = DIL, so the output keeps the input's size): the halo
 // grows to (TH + 2*DIL) x (TW + 2*DIL) and the tap offsets are multiplied by DIL; nothing else changes.
-template <typename T, int NT, int CPG, bool BNS, int DIL = 1>
-__global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_mfma_kernel(
+//
+// WS (wave-specialised, 32-channel chunks only): the workgroup has 8 waves.  Waves 4-7 are
+// producers: they stage the halo and the weights of stage s+1 (global -> registers -> affine ->
+// LDS) while waves 0-3, the consumers, run the MFMAs of stage s from the other of two LDS
+// buffers; one barrier per stage.  A stage's vector work and its matrix work then overlap on
+// every SIMD (one producer and one consumer wave each) instead of alternating: measured on the
+// deep layers, the phases of the single-role kernel add up (two workgroups per CU barely
+// overlap), which held them to a quarter of the MFMA rate.
+template <typename T, int NT, int CPG, bool BNS, int DIL = 1, bool WS = false>
+__global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_blocks(NT, CPG)) void conv3x3_mfma_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ wp, const float* __restrict__ bias,
     T* __restrict__ za, T* __restrict__ zb, float* __restrict__ partials, int B, int H, int W, int Cin, int Cs,
     int n_chunks_a, int Cout, int Cout_a, int n_chunks, int nt_total, int tiles_x, int tiles_y, int n_tiles,
@@ -272,22 +286,28 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   constexpr int NSTORE = PAIR ? NT / 2 : NT;
   constexpr unsigned OOB = 0x7FFFFFFFu;
 
+  static_assert(!WS || (CPG == 4 && DIL == 1), "the wave-specialised form exists for 32-channel chunks, no dilation");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HALO_BYTES = HP * halo_pstride<CPG>() + 16;     // padded rows + 1 dummy slot
-  unsigned char* halo = smem;
+  constexpr int BUF_BYTES = HALO_BYTES + W_VECS * 16;           // one stage: halo + weight fragments
+  unsigned char* halo = smem;                                   // (WS: re-pointed at the stage's buffer)
   uint4* wl = reinterpret_cast<uint4*>(smem + HALO_BYTES);
-  float* biasl = reinterpret_cast<float*>(wl + W_VECS);         // [NT*16], zero beyond Cout
+  float* biasl = reinterpret_cast<float*>(smem + (WS ? 2 : 1) * BUF_BYTES);   // [NT*16], zero beyond Cout
   float* aff = biasl + NT * 16;                                 // [2][Cin] (scale, shift) of a lazy input
   float* bnt = aff + 2 * Cin;                                   // [4][NT*16] (scale, shift, mean, rstd) of bnz
   __shared__ float red[4][2][NT * 16];
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  // WS: both roles number their threads 0..255, so the staging and the fragment code below are
+  // the same in either form
+  const bool producer = WS && threadIdx.x >= CM_THREADS;
+  const int tid = WS ? (int)(threadIdx.x & (CM_THREADS - 1)) : (int)threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kg = lane >> 4;
   const int n0 = blockIdx.y * NT;                 // first n-tile of this workgroup
 #if MIS_TIMELINE
   int tl_n = 0;
   const int tl_slot = (tid != 0 || blockIdx.y != 0) ? -1
+                      : WS ? (blockIdx.x == 0 ? (producer ? 1 : 0) : (blockIdx.x == gridDim.x - 1 && !producer) ? 2 : -1)
                       : blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : blockIdx.x == gridDim.x - 1 ? 2 : -1;
   TL_STAMP(1)
 #endif
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
 
   // tile-invariant staging state of this lane's halo elements: kept in registers, except in
   // the widest variant (no registers to spare) which recomputes it per stage
-  constexpr bool PRE = !(NT == 4 && CPG == 4);
+  constexpr bool PRE = WS || !(NT == 4 && CPG == 4);
   constexpr bool PRE_REL = PRE || (MIS_PRE_REL != 0);      // the widest variant keeps only the offsets
   int tid_l = tid;        // laundered per stage when !PRE, so the recomputation is not hoisted (and spilled)
   // (unsigned arithmetic: divisions by the compile-time halo width become a multiply-high and a shift)
@@ -365,7 +385,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   // write-heavy layers: reads queued behind a saturated store path otherwise stall the pipeline
   // (time = read phase + write phase instead of their maximum).
   constexpr bool AFF_REGS = (CM_THREADS % CPG == 0) && (MIS_AFF_REGS != 0);
-  constexpr bool DEEP = (CPG < 4) && (MIS_DEEP != 0) && !BNS && DIL == 1;   // (the fused-sums epilogue twice over would spill)
+  constexpr bool DEEP = (CPG < 4) && (MIS_DEEP != 0) && !BNS && DIL == 1 && !WS;   // (the fused-sums epilogue twice over would spill)
   u32x4 hreg[HALO_IT], hregB[DEEP ? HALO_IT : 1], wreg[W_IT];
 #define HREG hreg
   const __amdgpu_buffer_rsrc_t wrs =
@@ -547,6 +567,23 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
     }                                                                                                    \
   }
 
+  // this workgroup's contiguous tile range
+  const int nb_ = gridDim.x, q_ = n_tiles / nb_, r_ = n_tiles % nb_;
+  const int bx = blockIdx.x;
+  const int t_begin = bx * q_ + (bx < r_ ? bx : r_);
+  const int t_count = q_ + (bx < r_ ? 1 : 0);
+  TilePos cur;
+  cur.tx = t_begin % tiles_x;
+  cur.ty = (t_begin / tiles_x) % tiles_y;
+  cur.b = t_begin / (tiles_x * tiles_y);
+
+  if constexpr (WS) {
+    // the producers' first requests go out before the tables below are filled
+    if (producer) {
+      LOAD_HALO(cur, 0, t_count > 0)
+      LOAD_W(0, t_count > 0)
+    }
+  }
   for (int i = tid; i < NT * 16; i += CM_THREADS) {
     const int co = n0 * 16 + i;
     biasl[i] = (bias && co < Cout) ? bias[co] : 0.f;
@@ -565,16 +602,6 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
       bnt[i] = (co < Cout) ? bn_aff[(i / (NT * 16)) * Cout + co] : 0.f;
     }
   }
-  // this workgroup's contiguous tile range
-  const int nb_ = gridDim.x, q_ = n_tiles / nb_, r_ = n_tiles % nb_;
-  const int bx = blockIdx.x;
-  const int t_begin = bx * q_ + (bx < r_ ? bx : r_);
-  const int t_count = q_ + (bx < r_ ? 1 : 0);
-  TilePos cur;
-  cur.tx = t_begin % tiles_x;
-  cur.ty = (t_begin / tiles_x) % tiles_y;
-  cur.b = t_begin / (tiles_x * tiles_y);
-
   // Weights that fit one chunk stay in LDS for the whole kernel.  With fewer than 4 groups per
   // position that is always so and they are staged here, once; otherwise (runtime chunk count)
   // they travel through the stage pipeline below.
@@ -608,12 +635,13 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
         }                                                                                                \
       }                                                                                                  \
       Frag xa[2][MT], wf[2][NT];                                                                         \
-      if constexpr (NT < 4 && !(MIS_CSE_14 && NT == 1 && CPG == 4)) {                                       \
+      if constexpr ((NT < 4 || (WS && MIS_WS_FRAG2)) && !(MIS_CSE_14 && NT == 1 && CPG == 4)) {             \
         /* fragments of step s+1 are fetched from LDS while the MFMAs of step s run (two register */     \
         /* sets); the scheduling barrier keeps the compiler from hoisting every step's reads up */       \
         LOAD_FRAGS(0, 0)                                                                                 \
         _Pragma("unroll") for (int s = 0; s < ((MIS_DBG & 8) ? 1 : NS); s++) {                           \
           if (s + 1 < NS) LOAD_FRAGS(s + 1, (s + 1) & 1)                                                 \
+          if constexpr (WS || MIS_PIN_FRAGS) __builtin_amdgcn_sched_barrier(0); /* reads first: a step of MFMAs covers their latency */ \
           _Pragma("unroll") for (int n = 0; n < NT; n++)                                                 \
             _Pragma("unroll") for (int m = 0; m < MT; m++)                                               \
               mfma_step(wf[s & 1][n], xa[s & 1][m], acc[m][n]);                                          \
@@ -676,7 +704,74 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
   for (int m = 0; m < MT; m++)
 #pragma unroll
     for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (DEEP) {
+  if constexpr (WS) {
+    // Stage s = (tile, chunk) number s of this workgroup's range, in LDS buffer s & 1.
+    const int S = t_count * n_chunks;
+#define SET_BUF(BUFI)                                                                                    \
+  {                                                                                                      \
+    halo = smem + (BUFI) * BUF_BYTES;                                                                    \
+    wl = reinterpret_cast<uint4*>(halo + HALO_BYTES);                                                    \
+  }
+    __syncthreads();          // the tables above (affine, bias) are read by the first stage's staging
+    if (producer) {
+      // `ld`: the stage whose loads are in flight (or next to be issued); the stage being stored
+      // is the one loaded last, so its position is `ld` before the advance
+      TilePos ld = cur;
+      int ldc = 0;
+#define ADVANCE_LD()                                                                                     \
+  if (++ldc == n_chunks) {                                                                               \
+    ldc = 0;                                                                                             \
+    ld.next(tiles_x, tiles_y);                                                                           \
+  }
+      SET_BUF(0)                 /* (stage 0 was requested before the tables were filled) */
+      STORE_HALO(ld, ldc)
+      STORE_W()
+      ADVANCE_LD()
+      LOAD_HALO(ld, ldc, 1 < S)
+      LOAD_W(ldc, 1 < S)
+      __syncthreads();
+      for (int s = 0; s < S; s++) {
+        TL_STAMP(10)
+        if (s + 1 < S) {
+          TL_WAIT_LOADS()
+          SET_BUF((s + 1) & 1)
+          STORE_HALO(ld, ldc)
+          // weights that fit one chunk are the same in every stage: both buffers hold them after two stages
+          if (!w_resident || s == 0) STORE_W()
+        }
+        TL_STAMP(12)
+        ADVANCE_LD()
+        LOAD_HALO(ld, ldc, s + 2 < S)
+        LOAD_W(ldc, !w_resident && s + 2 < S)
+        TL_STAMP(14)
+        __syncthreads();
+      }
+#undef ADVANCE_LD
+    } else {
+      const bool live = true;
+      int chunk = 0;
+      __syncthreads();
+      for (int s = 0; s < S; s++) {
+        TL_STAMP(14)
+        SET_BUF(s & 1)
+        if (chunk == 0) {
+          STAGE_MFMA(true)
+        } else {
+          STAGE_MFMA(false)
+        }
+        TL_STAMP(15)
+        __syncthreads();       // the producers may overwrite this buffer; the epilogue below needs no LDS buffer
+        TL_STAMP(13)
+        if (++chunk == n_chunks) {
+          chunk = 0;
+          EPILOGUE()
+          cur.next(tiles_x, tiles_y);
+          TL_STAMP(20)
+        }
+      }
+    }
+#undef SET_BUF
+  } else if constexpr (DEEP) {
     // Two tiles per trip, one per register set; two leading load-only halves (it = -2, -1) give
     // every path into a wait the same shape, as above.  `cur` = the tile computed, `nxt` = the
     // tile requested (two ahead).
@@ -732,19 +827,19 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
 #undef LOAD_FRAGS
 
   if (partials) {
-    // sum over the 16 pixel lanes that share a channel quad, then over the 4 waves
+    // sum over the 16 pixel lanes that share a channel quad, then over the 4 (consumer) waves
 #pragma unroll
     for (int n = 0; n < NT; n++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const float a = row16_sum(s1[n][r]), q = row16_sum(s2[n][r]);
-        if (col == 0) {
+        if (col == 0 && !producer) {
           red[wid][0][n * 16 + 4 * kg + r] = a;
           red[wid][1][n * 16 + 4 * kg + r] = q;
         }
       }
     __syncthreads();
-    if (tid < 2 * NT * 16) {
+    if (tid < 2 * NT * 16 && !producer) {
       const int which = tid / (NT * 16), c = tid % (NT * 16);
       const float v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
       const int co = n0 * 16 + c;
@@ -766,6 +861,7 @@ __global__ __launch_bounds__(CM_THREADS, fwd_min_blocks(NT, CPG)) void conv3x3_m
 struct FwdPlan {
   int CPG, NT, n_chunks, nt_total, grid_x, grid_y, tiles_x, tiles_y, n_tiles;
   size_t lds;
+  bool ws;        // wave-specialised form (8 waves, two LDS stage buffers, one workgroup per CU)
 };
 
 // Workgroups of one variant that fit a CU together (registers and LDS), asked from the runtime
@@ -794,6 +890,16 @@ int fwd_resident(int NT, int CPG, size_t lds) {
   if (c == 0) c = NT == 4 ? fwd_resident_k<T, 4>(CPG, lds) : NT == 2 ? fwd_resident_k<T, 2>(CPG, lds)
                                                                      : fwd_resident_k<T, 1>(CPG, lds);
   return c;
+}
+
+// Largest problem (16x16-pixel tiles) that takes the wave-specialised form; MIS_CONV_WS_TILES overrides (tuning).
+inline int ws_max_tiles() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MIS_CONV_WS_TILES");
+    v = e ? atoi(e) : (1 << 30);
+  }
+  return v;
 }
 
 // Ca_in: channels of the first input tensor (== Cin for one tensor); Cout_a: channels of the
@@ -830,21 +936,29 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
     while ((Cout_a / 16) % p.NT != 0) p.NT /= 2;
     if (sizeof(T) == 2 && (Cout - Cout_a) % 8 != 0) p.NT = 1;
   }
-  {
+  // MIS_CONV_WS=0 (tuning): never the wave-specialised form
+  static int ws_mode = -1;
+  if (ws_mode < 0) {
+    const char* e = getenv("MIS_CONV_WS");
+    ws_mode = e ? atoi(e) : 1;
+  }
+  const int tiles16 = B * ((W + 15) / 16) * ((H + 15) / 16);
+  p.ws = ws_mode != 0 && p.CPG == 4 && p.NT >= 2 && dil == 1 && tiles16 <= ws_max_tiles();
+  if (!p.ws) {
     // few pixels (the center layers): 64-channel slices would leave one workgroup per CU; 32-channel
     // slices double the workgroups, and two resident per CU hide each other's staging (measured
     // 15-25 % on those layers; with >= 2 workgroups per CU already, the wider slice is faster)
-    const int tiles = B * ((W + 15) / 16) * ((H + 15) / 16);
-    if (p.NT == 4 && tiles * (p.nt_total / 4) < 512) p.NT = 2;
+    if (p.NT == 4 && tiles16 * (p.nt_total / 4) < 512) p.NT = 2;
   }
   p.grid_y = p.nt_total / p.NT;
   const int MX = fwd_mx(p.NT, p.CPG), TW = 16 * MX, TH = 4 * (fwd_mt(p.NT, p.CPG) / MX), HW_ = TW + 2;
   p.tiles_x = (W + TW - 1) / TW;
   p.tiles_y = (H + TH - 1) / TH;
   p.n_tiles = B * p.tiles_x * p.tiles_y;
-  p.lds = (size_t)(TH + 2 * dil) * (TW + 2 * dil) * (p.CPG == 4 ? 96 : (p.CPG | 1) * 16) + 16 +
-          (size_t)nsteps_of(p.CPG) * p.NT * 1024 +
+  p.lds = (p.ws ? 2 : 1) * ((size_t)(TH + 2 * dil) * (TW + 2 * dil) * (p.CPG == 4 ? 96 : (p.CPG | 1) * 16) + 16 +
+                            (size_t)nsteps_of(p.CPG) * p.NT * 1024) +
           (size_t)p.NT * 16 * 4 + 2 * (size_t)Cin * 4 + 4 * (size_t)p.NT * 16 * 4;
+  if (p.ws && p.lds > 160 * 1024) return false;
   // Total workgroups per launch: as many as are resident at once on 256 CUs, so the persistent
   // workgroups run as one round (a second, partly filled round costs a whole tile range: 10-25 %
   // on the 128^2 and 256^2 layers).  MIS_CONV_GRID overrides (tuning).
@@ -855,9 +969,15 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
   }
   // (The 8-channel-input variants stream many tiles per workgroup and measured best at 768 whatever
   // their residency: shorter ranges balance better than one round of long ones.)
-  const int target = forced >= 64 ? forced : p.CPG == 1 ? 768 : 256 * fwd_resident<T>(p.NT, p.CPG, p.lds);
+  const int target = forced >= 64 ? forced : p.ws ? 256 : p.CPG == 1 ? 768 : 256 * fwd_resident<T>(p.NT, p.CPG, p.lds);
   int gx = target / p.grid_y;
-  if (gx < 256) gx = 256;
+  if (p.ws) {
+    // one workgroup per CU, all resident at once: ceil so that no CU is left without one
+    gx = (target + p.grid_y - 1) / p.grid_y;
+    if (gx < 1) gx = 1;
+  } else if (gx < 256) {
+    gx = 256;
+  }
   if (gx > p.n_tiles) gx = p.n_tiles;
   p.grid_x = gx;
   return true;
@@ -881,11 +1001,18 @@ void launch_fwd_k(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
              : a.dil == 2 ? conv3x3_mfma_kernel<T, NT, CPG, false, 2>
              : a.dil == 3 ? conv3x3_mfma_kernel<T, NT, CPG, false, 3>
                           : conv3x3_mfma_kernel<T, NT, CPG, false, 1>;
+  int threads = CM_THREADS;
+  if constexpr (CPG == 4 && NT >= 2) {
+    if (p.ws) {
+      kfn = a.bnz ? conv3x3_mfma_kernel<T, NT, 4, true, 1, true> : conv3x3_mfma_kernel<T, NT, 4, false, 1, true>;
+      threads = 2 * CM_THREADS;
+    }
+  }
   if (p.lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
   const int Cin = a.in.channels(), Cout = a.out.channels();
   const int n_chunks_a = a.in.xb ? a.in.Ca / (4 * Mf<T>::G) : p.n_chunks;
-  kfn<<<dim3(p.grid_x, p.grid_y), CM_THREADS, p.lds, st>>>(
+  kfn<<<dim3(p.grid_x, p.grid_y), threads, p.lds, st>>>(
       (const T*)a.in.xa, (const T*)a.in.xb, (const T*)a.wp, a.bias, (T*)a.out.za, (T*)a.out.zb, a.partials, a.B, a.H,
       a.W, Cin, a.in.Ca, n_chunks_a, Cout, a.out.Ca, p.n_chunks, p.nt_total, p.tiles_x, p.tiles_y, p.n_tiles,
       a.in.affa, a.in.affb, (const T*)a.bnz, a.bn_aff);
@@ -1262,15 +1389,26 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   cur.tx = t_begin % tiles_x;
   cur.ty = (t_begin / tiles_x) % tiles_y;
   cur.b = t_begin / (tiles_x * tiles_y);
+#if MIS_TIMELINE
+  int tl_n = 0;
+  const int tl_slot = (tid != 0) ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : blockIdx.x == gridDim.x - 1 ? 2 : -1;
+  TL_STAMP(2)
+#endif
   WG_LOAD(cur, t_count > 0)
   for (int it = 0; it < t_count; it++) {
     TilePos nxt = cur;
     nxt.next(tiles_x, tiles_y);
+    TL_STAMP(10)
     __syncthreads();
+    TL_STAMP(11)
+    TL_WAIT_LOADS()
     WG_STORE(cur)
+    TL_STAMP(12)
     __syncthreads();
+    TL_STAMP(13)
     WG_LOAD(nxt, it + 1 < t_count)
     __builtin_amdgcn_sched_barrier(0);     // the loads stay ahead of the MFMAs
+    TL_STAMP(14)
 
     for (int r = wk; r < TH; r += WK) {
       if constexpr (sizeof(T) == 2) {
@@ -1311,10 +1449,12 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
         }
       }
     }
+    TL_STAMP(15)
     cur = nxt;
   }
 #undef WG_LOAD
 #undef WG_STORE
+  TL_STAMP(20)
 
   // sum the WK row-split waves through LDS (wave wk=0 of each (wco,wci) keeps the total)
   if constexpr (WK > 1) {
@@ -1355,6 +1495,10 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
             *reinterpret_cast<f32x4*>(sl + ((int64_t)t * Cin + ci) * Cout + co) = acc[t][mo][ni];
         }
   }
+#if MIS_TIMELINE
+  TL_STAMP(30)
+  if (tl_slot >= 0) mis_tl_buf[tl_slot][1023] = (unsigned long long)tl_n;
+#endif
 }
 
 // dw[co][ci][tap] = sum_s slab[s][tap][ci][co].  RL row lanes x (1024/RL) columns per workgroup:

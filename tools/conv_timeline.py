@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("layer")
     ap.add_argument("--dgrad", action="store_true")
+    ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--lazy", action="store_true")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dump", type=int, default=0)
@@ -36,6 +37,9 @@ def main():
     b = torch.zeros(co, device=dev)
     ss = torch.rand(2, ci, device=dev) if a.lazy else None
     run = lambda: F_.conv3x3_raw(x, wf, b, co, False if a.dgrad else "partial", ss)
+    if a.wgrad:
+        dz = torch.randn(a.batch, co, hw, hw, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+        run = lambda: F_.conv3x3_wgrad_raw(x, dz, ss)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -46,7 +50,7 @@ def main():
     lib = ctypes.CDLL(os.environ["MISAMD_LIBRARY"])
     rc = lib.mis_debug_timeline(buf.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0, rc
-    print(f"{name} {ci}->{co}@{hw} {'dgrad' if a.dgrad else 'fwd'} lazy={a.lazy}: {e0.elapsed_time(e1) * 1e3:.1f} us (event)")
+    print(f"{name} {ci}->{co}@{hw} {'wgrad' if a.wgrad else 'dgrad' if a.dgrad else 'fwd'} lazy={a.lazy}: {e0.elapsed_time(e1) * 1e3:.1f} us (event)")
     for slot in range(3):
         n = int(buf[slot, 1023])
         if n == 0:
