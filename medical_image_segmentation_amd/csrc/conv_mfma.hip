@@ -1196,6 +1196,11 @@ constexpr int WG_TW = 32;
 template <typename T> struct WgT;
 template <> struct WgT<bf16> { static constexpr int TH = 8; };
 template <> struct WgT<float> { static constexpr int TH = 4; };
+// Tile height of a variant: the wave-specialised form holds two stages in LDS, so its 64x64-channel
+// block takes 4-row tiles.
+template <typename T>
+constexpr int wg_tile_h(bool ws, int cto, int cti) { return (ws && cto * cti >= 4096) ? 4 : WgT<T>::TH; }
+constexpr int WG_PRODUCERS = 256;      // staging threads of the wave-specialised form
 
 // LDS tiles are [position][CT channels] with rows padded to an odd multiple of 32 bytes, so
 // that the 8 consecutive positions one half-wave transposed read touches fall on 8 distinct
@@ -1222,30 +1227,39 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int lane_of
 
 // The four-wave (light-channel) variants are bound by memory latency: three resident workgroups per
 // CU (<= 168 registers) keep a third more bytes in flight than two and run 15-25% faster.
-template <typename T, int MTO, int NTI, int WCO, int WCI, int WK, int DIL = 1>
-__global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x3_wgrad_mfma_kernel(
+//
+// WS (wave-specialised): 4 extra producer waves stage tile t+1 (global -> registers -> affine -> LDS)
+// into the second of two LDS stages while the MFMA waves work on tile t; one barrier per tile.
+// In the single-role form the staging and the MFMAs of a tile alternate (measured: 45 % of a
+// tile's time outside the MFMA phase on the deep layers).
+template <typename T, int MTO, int NTI, int WCO, int WCI, int WK, int DIL = 1, bool WS = false>
+__global__ __launch_bounds__(64 * WCO * WCI * WK + (WS ? WG_PRODUCERS : 0), (WS ? 1 : WK == 4 ? 3 : 1)) void conv3x3_wgrad_mfma_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, int Ca, const T* __restrict__ dz, float* __restrict__ slab,
     int B, int H, int W, int Cin, int Cout, int n_ci_blocks, int tiles_x, int tiles_y, int n_tiles,
     const float* __restrict__ affa, const float* __restrict__ affb, int nsplit, int nout) {
-  constexpr int NTHR = 64 * WCO * WCI * WK;
+  constexpr int NTHR = 64 * WCO * WCI * WK;            // MFMA threads
+  constexpr int STHR = WS ? WG_PRODUCERS : NTHR;       // staging threads
   constexpr int G = Mf<T>::G;
-  constexpr int TH = WgT<T>::TH;
+  constexpr int TH = wg_tile_h<T>(WS, WCO * MTO * 16, WCI * NTI * 16);
   constexpr int HWW = WG_TW + 2 * DIL;           // halo width (34 without dilation)
   constexpr int PH = (TH + 2 * DIL) * HWW;       // halo positions
   constexpr int PZ = TH * WG_TW;                 // dz positions
   constexpr int CTO = WCO * MTO * 16, CTI = WCI * NTI * 16;
   constexpr int XVP = CTI / G, ZVP = CTO / G;    // 16-byte vectors per position
   constexpr int XV = PH * XVP, ZV = PZ * ZVP;
-  constexpr int XIT = (XV + NTHR - 1) / NTHR, ZIT = (ZV + NTHR - 1) / NTHR;
+  constexpr int XIT = (XV + STHR - 1) / STHR, ZIT = (ZV + STHR - 1) / STHR;
   constexpr int RSX = padded_row_bytes(CTI * (int)sizeof(T)), RSZ = padded_row_bytes(CTO * (int)sizeof(T));
+  constexpr int STAGE_BYTES = PH * RSX + 16 + PZ * RSZ + 16;   // one stage: x halo + dz tile (+ dummy slots)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xh = smem;                      // [PH] rows of RSX bytes (CTI channels + pad), + 1 dummy slot
   unsigned char* zt = smem + PH * RSX + 16;      // [PZ] rows of RSZ bytes, + 1 dummy slot
-  float* aff = reinterpret_cast<float*>(zt + PZ * RSZ + 16);   // [2][CTI] (scale, shift) of this block's x channels
+  float* aff = reinterpret_cast<float*>(smem + (WS ? 2 : 1) * STAGE_BYTES);   // [2][CTI] (scale, shift) of this block's x channels
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wk = wid % WK, wci = (wid / WK) % WCI, wco = wid / (WK * WCI);
+  const bool producer = WS && threadIdx.x >= NTHR;
+  // `tid` numbers the staging threads where the staging code uses it (WS: the producers, 0..255)
+  const int tid = producer ? (int)threadIdx.x - NTHR : (int)threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wk = producer ? WK : wid % WK, wci = (wid / WK) % WCI, wco = producer ? 0 : wid / (WK * WCI);
   // One-dimensional grid of nsplit * nout workgroups.  The nout (co, ci) blocks of one tile range
   // read the same x and dz tiles; consecutive workgroup ids go round the 8 XCDs (each with its own
   // L2), so with nsplit a multiple of 8 the blocks of a range are given ids 8 apart: same XCD, launched
@@ -1289,7 +1303,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   int x_px[XIT], z_px[ZIT], x_lds[XIT], z_lds[ZIT];
 #pragma unroll
   for (int i = 0; i < XIT; i++) {
-    const int v = tid + i * NTHR, pos = v / XVP, cv = v % XVP;
+    const int v = tid + i * STHR, pos = v / XVP, cv = v % XVP;
     const bool valid = v < XV && cl0 + cv * G < Csrc;
     x_rel[i] = (unsigned)((((pos / HWW) * W + pos % HWW) * Csrc + cl0 + cv * G) * (int)sizeof(T));
     x_px[i] = valid ? pos % HWW : (1 << 28);
@@ -1297,7 +1311,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   }
 #pragma unroll
   for (int i = 0; i < ZIT; i++) {
-    const int v = tid + i * NTHR, pos = v / ZVP, cv = v % ZVP;
+    const int v = tid + i * STHR, pos = v / ZVP, cv = v % ZVP;
     const bool valid = v < ZV && co0 + cv * G < Cout;
     z_rel[i] = (unsigned)((((pos / WG_TW) * W + pos % WG_TW) * Cout + co0 + cv * G) * (int)sizeof(T));
     z_px[i] = valid ? pos % WG_TW : (1 << 28);
@@ -1306,7 +1320,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
 
   u32x4 xr[XIT], zr[ZIT];
   // (the variants at their register limit would spill the 16 extra values: they keep the per-element form)
-  constexpr bool WG_AFF_REGS = (NTHR % XVP == 0) && (MIS_AFF_REGS != 0) && !(NTI == 2 && (WK == 4 || WCO == 2));
+  constexpr bool WG_AFF_REGS = (STHR % XVP == 0) && (MIS_AFF_REGS != 0) && !(NTI == 2 && (WK == 4 || WCO == 2));
   const int ximg_bytes = H * W * Csrc * (int)sizeof(T), zimg_bytes = H * W * Cout * (int)sizeof(T);
   // a dead stage (past the last tile) shifts x far left: nothing loads
 #define WG_LOAD(P, LIVE)                                                                                \
@@ -1346,7 +1360,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
       const int gy0_ = (P).ty * TH - DIL, gx0_ = (P).tx * WG_TW - DIL;                                  \
       _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                 \
         const u32x4 raw_ = xr[i];                                                                       \
-        const unsigned pos = ((unsigned)tid + i * NTHR) / XVP;                                          \
+        const unsigned pos = ((unsigned)tid + i * STHR) / XVP;                                          \
         const bool in_ = (unsigned)(gy0_ + (int)(pos / HWW)) < (unsigned)H &&                           \
                          (unsigned)(gx0_ + (int)(pos % HWW)) < (unsigned)W;                             \
         const u32x4 act_ = affine_relu_regs<T, G>(raw_, sc_, sh_);                                      \
@@ -1358,7 +1372,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
       _Pragma("unroll") for (int i = 0; i < XIT; i++) {                                                 \
         u32x4 val = xr[i];                                                                              \
         if (x_aff) {                                                                                    \
-          const int v = tid + i * NTHR, pos = v / XVP, cv = v % XVP;                                    \
+          const int v = tid + i * STHR, pos = v / XVP, cv = v % XVP;                                    \
           const int gy = (P).ty * TH - DIL + pos / HWW, gx = (P).tx * WG_TW - DIL + pos % HWW;          \
           if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && cl0 + cv * G < Csrc)          \
             val = affine_relu_raw<T>(val, aff + cv * G, aff + CTI + cv * G);                            \
@@ -1375,7 +1389,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   const int offz = k_pixel(lg, 0, lq) * RSZ + 8 * lp + wco * MTO * 32;
 
   if (x_aff) {
-    for (int i = tid; i < 2 * CTI; i += NTHR) {
+    for (int i = threadIdx.x; i < 2 * CTI; i += blockDim.x) {
       const int c = cl0 + i % CTI;
       aff[i] = (c < Csrc) ? x_aff[(i / CTI) * Csrc + c] : 0.f;
     }
@@ -1391,9 +1405,94 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
   cur.b = t_begin / (tiles_x * tiles_y);
 #if MIS_TIMELINE
   int tl_n = 0;
-  const int tl_slot = (tid != 0) ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : blockIdx.x == gridDim.x - 1 ? 2 : -1;
+  const int tl_slot = (tid != 0) ? -1
+                      : WS ? (blockIdx.x == 0 ? (producer ? 1 : 0) : (blockIdx.x == gridDim.x - 1 && !producer) ? 2 : -1)
+                      : blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : blockIdx.x == gridDim.x - 1 ? 2 : -1;
   TL_STAMP(2)
 #endif
+#define WG_MFMA_ROWS() \
+  { \
+    for (int r = wk; r < TH; r += WK) { \
+      if constexpr (sizeof(T) == 2) { \
+        bf16x8 a[MTO]; \
+    _Pragma("unroll") \
+        for (int mo = 0; mo < MTO; mo++) a[mo] = tr_frag<RSZ>(zt, offz, r * WG_TW * RSZ + mo * 32); \
+    _Pragma("unroll") \
+        for (int t = 0; t < 9; t++) { \
+    _Pragma("unroll") \
+          for (int ni = 0; ni < NTI; ni++) { \
+            const bf16x8 bq = tr_frag<RSX>(xh, offx, (r * HWW + ((t / 3) * HWW + (t % 3)) * DIL) * RSX + ni * 32); \
+    _Pragma("unroll") \
+            for (int mo = 0; mo < MTO; mo++) \
+              acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mo], bq, acc[t][mo][ni], 0, 0, 0); \
+          } \
+        } \
+      } else { \
+    _Pragma("unroll 2") \
+        for (int kk = 0; kk < WG_TW / 4; kk++) { \
+          const int px = 4 * kk + (lane >> 4); \
+          float a[MTO]; \
+    _Pragma("unroll") \
+          for (int mo = 0; mo < MTO; mo++) { \
+            const int pos = r * WG_TW + px, c = (wco * MTO + mo) * 16 + (lane & 15); \
+            a[mo] = *reinterpret_cast<const float*>(zt + pos * RSZ + c * 4); \
+          } \
+    _Pragma("unroll") \
+          for (int t = 0; t < 9; t++) { \
+    _Pragma("unroll") \
+            for (int ni = 0; ni < NTI; ni++) { \
+              const int pos = (r + (t / 3) * DIL) * HWW + (t % 3) * DIL + px, c = (wci * NTI + ni) * 16 + (lane & 15); \
+              const float bq = *reinterpret_cast<const float*>(xh + pos * RSX + c * 4); \
+    _Pragma("unroll") \
+              for (int mo = 0; mo < MTO; mo++) \
+                acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo], bq, acc[t][mo][ni], 0, 0, 0); \
+            } \
+          } \
+        } \
+      } \
+    } \
+  }
+  if constexpr (WS) {
+#define WG_SET_BUF(BUFI)                                                                                \
+  {                                                                                                     \
+    xh = smem + (BUFI) * STAGE_BYTES;                                                                   \
+    zt = xh + PH * RSX + 16;                                                                            \
+  }
+    if (producer) {
+      WG_LOAD(cur, t_count > 0)           // (requested before the affine table is visible)
+      __syncthreads();
+      WG_SET_BUF(0)
+      WG_STORE(cur)
+      cur.next(tiles_x, tiles_y);
+      WG_LOAD(cur, 1 < t_count)
+      __syncthreads();
+      for (int it = 0; it < t_count; it++) {
+        TL_STAMP(10)
+        if (it + 1 < t_count) {
+          TL_WAIT_LOADS()
+          WG_SET_BUF((it + 1) & 1)
+          WG_STORE(cur)
+        }
+        TL_STAMP(12)
+        cur.next(tiles_x, tiles_y);
+        WG_LOAD(cur, it + 2 < t_count)
+        TL_STAMP(14)
+        __syncthreads();
+      }
+    } else {
+      __syncthreads();
+      __syncthreads();
+      for (int it = 0; it < t_count; it++) {
+        TL_STAMP(14)
+        WG_SET_BUF(it & 1)
+        WG_MFMA_ROWS()
+        TL_STAMP(15)
+        __syncthreads();
+        TL_STAMP(13)
+      }
+    }
+#undef WG_SET_BUF
+  } else {
   WG_LOAD(cur, t_count > 0)
   for (int it = 0; it < t_count; it++) {
     TilePos nxt = cur;
@@ -1410,48 +1509,12 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK, (WK == 4 ? 3 : 1)) void conv3x
     __builtin_amdgcn_sched_barrier(0);     // the loads stay ahead of the MFMAs
     TL_STAMP(14)
 
-    for (int r = wk; r < TH; r += WK) {
-      if constexpr (sizeof(T) == 2) {
-        bf16x8 a[MTO];
-#pragma unroll
-        for (int mo = 0; mo < MTO; mo++) a[mo] = tr_frag<RSZ>(zt, offz, r * WG_TW * RSZ + mo * 32);
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-#pragma unroll
-          for (int ni = 0; ni < NTI; ni++) {
-            const bf16x8 bq = tr_frag<RSX>(xh, offx, (r * HWW + ((t / 3) * HWW + (t % 3)) * DIL) * RSX + ni * 32);
-#pragma unroll
-            for (int mo = 0; mo < MTO; mo++)
-              acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mo], bq, acc[t][mo][ni], 0, 0, 0);
-          }
-        }
-      } else {
-#pragma unroll 2
-        for (int kk = 0; kk < WG_TW / 4; kk++) {
-          const int px = 4 * kk + (lane >> 4);
-          float a[MTO];
-#pragma unroll
-          for (int mo = 0; mo < MTO; mo++) {
-            const int pos = r * WG_TW + px, c = (wco * MTO + mo) * 16 + (lane & 15);
-            a[mo] = *reinterpret_cast<const float*>(zt + pos * RSZ + c * 4);
-          }
-#pragma unroll
-          for (int t = 0; t < 9; t++) {
-#pragma unroll
-            for (int ni = 0; ni < NTI; ni++) {
-              const int pos = (r + (t / 3) * DIL) * HWW + (t % 3) * DIL + px, c = (wci * NTI + ni) * 16 + (lane & 15);
-              const float bq = *reinterpret_cast<const float*>(xh + pos * RSX + c * 4);
-#pragma unroll
-              for (int mo = 0; mo < MTO; mo++)
-                acc[t][mo][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mo], bq, acc[t][mo][ni], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
+    WG_MFMA_ROWS()
     TL_STAMP(15)
     cur = nxt;
   }
+  }
+#undef WG_MFMA_ROWS
 #undef WG_LOAD
 #undef WG_STORE
   TL_STAMP(20)
@@ -1546,12 +1609,12 @@ struct WgPlan {
   int cfg;          // 0: 1x1 tiles, K-split waves; 1: 2x1 (co 32 x ci 16); 2: 1x2; 3: 2x2 K-split; 4: 64x64 block
   int CTO, CTI, n_co_blocks, n_ci_blocks, tiles_x, tiles_y, n_tiles, nsplit;
   size_t lds;
+  bool ws;          // wave-specialised form (cfg 3 and 4, bf16, no dilation): producer waves + two LDS stages
 };
 
 template <typename T>
 bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1, int dil = 1) {
   constexpr int G = Mf<T>::G;
-  constexpr int TH = WgT<T>::TH;
   if (Cin % G != 0 || Cout % G != 0) return false;
   if ((int64_t)H * W * (Cin > Cout ? Cin : Cout) * (int64_t)sizeof(T) >= ((int64_t)1 << 31) - (1 << 22)) return false;
   if (Cout >= 64 && Cin >= 64) { p.cfg = 4; p.CTO = 64; p.CTI = 64; }
@@ -1559,6 +1622,14 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1, 
   else if (Cout > 16) { p.cfg = 1; p.CTO = 32; p.CTI = 16; }
   else if (Cin > 16) { p.cfg = 2; p.CTO = 16; p.CTI = 32; }
   else { p.cfg = 0; p.CTO = 16; p.CTI = 16; }
+  // MIS_WGRAD_WS=0 (tuning): never the wave-specialised form
+  static int ws_mode = -1;
+  if (ws_mode < 0) {
+    const char* e = getenv("MIS_WGRAD_WS");
+    ws_mode = e ? atoi(e) : 1;
+  }
+  p.ws = ws_mode != 0 && sizeof(T) == 2 && dil == 1 && p.cfg >= 3;
+  const int TH = wg_tile_h<T>(p.ws, p.CTO, p.CTI);
   if (Ca >= 0 && Ca != Cin && (Ca <= 0 || Ca % p.CTI != 0)) return false;   // channel tiles must not straddle the two inputs
   p.n_co_blocks = (Cout + p.CTO - 1) / p.CTO;
   p.n_ci_blocks = (Cin + p.CTI - 1) / p.CTI;
@@ -1577,7 +1648,7 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1, 
     const char* e = getenv("MIS_WGRAD_GRID");
     forced = e ? atoi(e) : 0;
   }
-  const int target = forced >= 64 ? forced : p.cfg == 4 ? 256 : p.cfg == 3 ? 512 : 768;
+  const int target = forced >= 64 ? forced : (p.cfg == 4 || p.ws) ? 256 : p.cfg == 3 ? 512 : 768;
   int ns = target / nout;
   const int ns_slab = (int)(act_bytes / dw_bytes);
   if (ns > ns_slab) ns = ns_slab;
@@ -1588,11 +1659,14 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1, 
   if (ns < 1) ns = 1;
   if (nout > 1 && ns >= 8) ns &= ~7;          // whole groups of 8: the kernel's XCD-aware id mapping
   p.nsplit = ns;
-  const size_t tiles = (size_t)(TH + 2 * dil) * (WG_TW + 2 * dil) * padded_row_bytes(p.CTI * (int)sizeof(T)) + 16 +
-                       (size_t)TH * WG_TW * padded_row_bytes(p.CTO * (int)sizeof(T)) + 16 + 2 * (size_t)p.CTI * 4;
+  const size_t stage = (size_t)(TH + 2 * dil) * (WG_TW + 2 * dil) * padded_row_bytes(p.CTI * (int)sizeof(T)) + 16 +
+                       (size_t)TH * WG_TW * padded_row_bytes(p.CTO * (int)sizeof(T)) + 16;
+  const size_t tiles = (p.ws ? 2 : 1) * stage + 2 * (size_t)p.CTI * 4;
   // K-split reduction scratch: one 9 x (tiles per wave) x 1 KiB region per (co,ci) wave group
-  const size_t redb = (size_t)9 * (p.CTO / 16) * (p.CTI / 16) * 64 * 16;
+  // (none in the wave-specialised 64x64 block: its waves do not split K)
+  const size_t redb = (p.ws && p.cfg == 4) ? 0 : (size_t)9 * (p.CTO / 16) * (p.CTI / 16) * 64 * 16;
   p.lds = tiles > redb ? tiles : redb;
+  if (p.lds > 160 * 1024) return false;
   return true;
 }
 
@@ -1623,14 +1697,31 @@ int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, f
                                                   H, W, Cin, Cout, p.n_ci_blocks, p.tiles_x, p.tiles_y,    \
                                                   p.n_tiles, in.affa, in.affb, p.nsplit, nout_blocks);     \
   }
-  switch (p.cfg) {
-    case 0: WG_LAUNCH(1, 1, 1, 1, 4); break;
-    case 1: WG_LAUNCH(2, 1, 1, 1, 4); break;
-    case 2: WG_LAUNCH(1, 2, 1, 1, 4); break;
-    case 3: WG_LAUNCH(2, 1, 1, 2, 2); break;
-    default: WG_LAUNCH(2, 2, 2, 2, 2); break;
+#define WG_LAUNCH_WS(MTO, NTI, WCO, WCI, WK)                                                               \
+  {                                                                                                        \
+    auto kfn = conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK, 1, true>;                              \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);   \
+    kfn<<<grid, 64 * WCO * WCI * WK + WG_PRODUCERS, p.lds, st>>>(                                          \
+        (const T*)in.xa, (const T*)in.xb, in.Ca, (const T*)dz, slab, B, H, W, Cin, Cout, p.n_ci_blocks,    \
+        p.tiles_x, p.tiles_y, p.n_tiles, in.affa, in.affb, p.nsplit, nout_blocks);                         \
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (p.ws) {
+      if (p.cfg == 3) WG_LAUNCH_WS(2, 1, 1, 2, 2)
+      else WG_LAUNCH_WS(2, 2, 2, 2, 1)
+    }
+  }
+  if (!p.ws) {
+    switch (p.cfg) {
+      case 0: WG_LAUNCH(1, 1, 1, 1, 4); break;
+      case 1: WG_LAUNCH(2, 1, 1, 1, 4); break;
+      case 2: WG_LAUNCH(1, 2, 1, 1, 4); break;
+      case 3: WG_LAUNCH(2, 1, 1, 2, 2); break;
+      default: WG_LAUNCH(2, 2, 2, 2, 2); break;
+    }
   }
 #undef WG_LAUNCH
+#undef WG_LAUNCH_WS
   MIS_CHECK_LAUNCH("conv3x3_wgrad_mfma_kernel");
   const int nout = 9 * Cin * Cout;
   const int nb_bias = bias.dbias ? cdiv(Cout, 32) : 0;
