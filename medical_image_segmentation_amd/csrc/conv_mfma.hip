@@ -892,12 +892,14 @@ int fwd_resident(int NT, int CPG, size_t lds) {
   return c;
 }
 
-// Largest problem (16x16-pixel tiles) that takes the wave-specialised form; MIS_CONV_WS_TILES overrides (tuning).
+// Largest problem (16x16-pixel tiles) that takes the wave-specialised form: beyond it the layers are
+// bandwidth-bound and several small workgroups per CU keep more bytes in flight than one large one
+// (measured on the 512^2 layers of A_UNet / RDAM_UNet).  MIS_CONV_WS_TILES overrides (tuning).
 inline int ws_max_tiles() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MIS_CONV_WS_TILES");
-    v = e ? atoi(e) : (1 << 30);
+    v = e ? atoi(e) : 1024;
   }
   return v;
 }
