@@ -232,6 +232,31 @@ int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int 
                       int Cin, int Cout, float* dw, const float* bias_rows, int n_bias_rows, float* dbias,
                       void* workspace, mis_stream_t stream);
 
+/* The weight gradient in two parts, for a caller that reduces the partial results of SEVERAL   */
+/* layers in ONE launch (autograd needs the weight gradients of a step only when the optimizer   */
+/* or a gradient exchange reads them: utils/train_and_eval.py:109-118; one small reduction       */
+/* launch per layer costs more than the work in it).  mis_conv3x3_wgrad_slabs writes *n_slabs     */
+/* partial gradients [n_slabs][9][Cin][Cout] float32 into `slabs`                                 */
+/* (mis_conv3x3_wgrad_workspace_bytes, Cin = Ca + Cb; the caller keeps them until the reduction)   */
+/* for a one- (xb NULL, Cb 0) or two-tensor input and dilation 1..3; MIS_ERR_UNSUPPORTED when the  */
+/* matrix-core kernels do not take the shape (*_supported tells; use mis_conv3x3_wgrad then).       */
+/* mis_wgrad_reduce_multi                                                                        */
+/* sums each job's slabs in a fixed order into dw [Cout][Cin][3][3] (and bias_rows into dbias, as  */
+/* the rider of mis_conv3x3_wgrad); `jobs` is a HOST array.  Results are bit-identical to          */
+/* mis_conv3x3_wgrad / mis_conv3x3_cat_wgrad / mis_conv3x3_dilated_wgrad.                          */
+typedef struct mis_wgrad_reduce_job {
+  const float* slabs;
+  float* dw;
+  const float* bias_rows;   /* [n_bias_rows][Cout] or NULL */
+  float* dbias;             /* [Cout] or NULL */
+  int n_slabs, Cin, Cout, n_bias_rows;
+} mis_wgrad_reduce_job;
+int mis_conv3x3_wgrad_slabs_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout, int dilation);
+int mis_conv3x3_wgrad_slabs(const void* xa, const float* xa_affine, const void* xb, const float* xb_affine,
+                            const void* dz, int dtype, int B, int H, int W, int Ca, int Cb, int Cout, int dilation,
+                            void* slabs, int* n_slabs, mis_stream_t stream);
+int mis_wgrad_reduce_multi(const mis_wgrad_reduce_job* jobs, int n_jobs, mis_stream_t stream);
+
 /* The same conv with DILATED taps: nn.Conv2d(kernel_size=3, padding=d, dilation=d), d = 2, 3 */
 /* — ResDConv.cbr2 / cbr3, model/utils/modules.py:440-445 (d = 1 is the plain conv).  The data  */
 /* gradient of a dilated conv is mis_conv3x3_dilated_fwd on the transposed weight image with    */

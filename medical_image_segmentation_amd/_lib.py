@@ -47,6 +47,9 @@ PROTOTYPES = {
     "mis_conv3x3_dgrad_bn_sums": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mis_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "mis_conv3x3_wgrad_slabs_supported": (_i, [_i] * 8),
+    "mis_conv3x3_wgrad_slabs": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_wgrad_reduce_multi": (_i, [_vp, _i, _vp]),
     "mis_conv3x3_dilated_supported": (_i, [_i] * 7),
     "mis_conv3x3_dilated_stats_rows": (_i, [_i] * 7),
     "mis_conv3x3_dilated_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -150,6 +150,40 @@ int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int 
   return conv3x3_direct_wgrad(x, x_affine, dz, dtype, B, H, W, Cin, Cout, dw, workspace, (hipStream_t)stream);
 }
 
+int mis_conv3x3_wgrad_slabs_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout, int dilation) {
+  if (B < 1 || H < 1 || W < 1 || Ca < 1 || Cb < 0 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
+  if (dilation < 1 || dilation > 3 || (Cb > 0 && dilation != 1) || force_direct()) return 0;
+  return (Cb > 0 ? conv3x3_wgrad_mfma_cat_supported(dtype, B, H, W, Ca, Cb, Cout)
+                 : conv3x3_wgrad_mfma_supported(dtype, B, H, W, Ca, Cout)) ? 1 : 0;
+}
+
+int mis_conv3x3_wgrad_slabs(const void* xa, const float* xa_affine, const void* xb, const float* xb_affine,
+                            const void* dz, int dtype, int B, int H, int W, int Ca, int Cb, int Cout, int dilation,
+                            void* slabs, int* n_slabs, mis_stream_t stream) {
+  MIS_REQUIRE(xa && dz && slabs && n_slabs, "conv3x3_wgrad_slabs: null pointer");
+  MIS_REQUIRE((xb != nullptr) == (Cb > 0), "conv3x3_wgrad_slabs: xb and Cb go together");
+  MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Ca >= 1 && Cb >= 0 && Cout >= 1, "conv3x3_wgrad_slabs: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_wgrad_slabs: bad dtype %d", dtype);
+  if (!mis_conv3x3_wgrad_slabs_supported(dtype, B, H, W, Ca, Cb, Cout, dilation)) {
+    mis_set_error("conv3x3_wgrad_slabs: %d+%d -> %d channels, dilation %d is not taken by the matrix-core kernels",
+                  Ca, Cb, Cout, dilation);
+    return MIS_ERR_UNSUPPORTED;
+  }
+  return conv3x3_wgrad_mfma_slabs(ConvIn{xa, xa_affine, Ca, xb, xb_affine, Cb}, dz, dtype, B, H, W, Cout, slabs,
+                                  n_slabs, (hipStream_t)stream, dilation);
+}
+
+int mis_wgrad_reduce_multi(const mis_wgrad_reduce_job* jobs, int n_jobs, mis_stream_t stream) {
+  MIS_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), "wgrad_reduce_multi: null job array");
+  for (int j = 0; j < n_jobs; j++) {
+    const mis_wgrad_reduce_job& jb = jobs[j];
+    MIS_REQUIRE(jb.slabs && jb.dw && jb.n_slabs >= 1 && jb.Cin >= 1 && jb.Cout >= 1, "wgrad_reduce_multi: bad job %d", j);
+    MIS_REQUIRE(!jb.dbias || (jb.bias_rows && jb.n_bias_rows >= 1), "wgrad_reduce_multi: job %d: dbias needs its partial rows", j);
+  }
+  if (n_jobs == 0) return MIS_OK;
+  return conv3x3_wgrad_reduce_multi(jobs, n_jobs, (hipStream_t)stream);
+}
+
 int mis_conv3x3_dilated_supported(int dtype, int B, int H, int W, int Cin, int Cout, int dilation) {
   if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
   if (dilation < 1 || dilation > 3 || force_direct()) return 0;

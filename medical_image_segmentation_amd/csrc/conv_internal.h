@@ -64,3 +64,7 @@ struct BiasRows {
 };
 int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, float* dw,
                        const BiasRows& bias, void* workspace, hipStream_t st, int dil = 1);
+// the same without the reduction: slabs [n_slabs][9][Cin][Cout] only, and their reduction for several layers at once
+int conv3x3_wgrad_mfma_slabs(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, void* slabs,
+                             int* n_slabs, hipStream_t st, int dil = 1);
+int conv3x3_wgrad_reduce_multi(const mis_wgrad_reduce_job* jobs, int n_jobs, hipStream_t st);

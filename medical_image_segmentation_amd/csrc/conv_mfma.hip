@@ -1569,20 +1569,15 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK + (WS ? WG_PRODUCERS : 0), (WS 
 // dw[co][ci][tap] = sum_s slab[s][tap][ci][co].  RL row lanes x (1024/RL) columns per workgroup:
 // many lanes per column when there are many splits and few outputs, one lane per column
 // (pure streaming) when the weight tensor is large and the splits few.  Fixed order.
+// One workgroup's share of that reduction: columns [blk*COLS, (blk+1)*COLS) of the 9*Cin*Cout outputs.
+// `smem` holds RL x (COLS+1) doubles (RL > 1).
 template <int RL>
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cin,
-                                                            int Cout, float* __restrict__ dw, int nblk_w,
-                                                            BiasRows bias) {
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slab, int nsplit, int Cin, int Cout,
+                                                   float* __restrict__ dw, int blk, double* smem) {
   constexpr int COLS = 1024 / RL;
-  if ((int)blockIdx.x >= nblk_w) {        // rider: the conv-bias gradient from its partial rows
-    __shared__ double bred[32][33];
-    reduce_rows_block(bias.rows, bias.n_rows, Cout, Cout, bias.dbias, (int)blockIdx.x - nblk_w, bred);
-    return;
-  }
-  __shared__ double red[RL > 1 ? RL : 1][RL > 1 ? COLS + 1 : 1];
   const int n = 9 * Cin * Cout;
   const int c = threadIdx.x % COLS, r = threadIdx.x / COLS;
-  const int j = blockIdx.x * COLS + c;
+  const int j = blk * COLS + c;
   double s = 0.0;
   if (j < n) {
     int i = r;
@@ -1594,17 +1589,69 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     for (; i < nsplit; i += RL) s += (double)slab[(int64_t)i * n + j];
   }
   if constexpr (RL > 1) {
-    red[r][c] = s;
+    smem[r * (COLS + 1) + c] = s;
     __syncthreads();
     if (r != 0) return;
     s = 0.0;
 #pragma unroll
-    for (int k = 0; k < RL; k++) s += red[k][c];
+    for (int k = 0; k < RL; k++) s += smem[k * (COLS + 1) + c];
   }
   if (j < n) {
     const int co = j % Cout, ci = (j / Cout) % Cin, tap = j / (Cout * Cin);
     dw[((int64_t)co * Cin + ci) * 9 + tap] = (float)s;
   }
+}
+
+constexpr int WGRAD_REDUCE_SMEM = 32 * 33 > 4 * 257 ? 32 * 33 : 4 * 257;     // doubles: the largest of the forms below
+
+template <int RL>
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int Cin,
+                                                            int Cout, float* __restrict__ dw, int nblk_w,
+                                                            BiasRows bias) {
+  __shared__ double sm[WGRAD_REDUCE_SMEM];
+  if ((int)blockIdx.x >= nblk_w) {        // rider: the conv-bias gradient from its partial rows
+    reduce_rows_block(bias.rows, bias.n_rows, Cout, Cout, bias.dbias, (int)blockIdx.x - nblk_w,
+                      reinterpret_cast<double(*)[33]>(sm));
+    return;
+  }
+  wgrad_reduce_block<RL>(slab, nsplit, Cin, Cout, dw, (int)blockIdx.x, sm);
+}
+
+// Rows per column and workgroups of one layer's reduction (the three forms above).
+struct WgReduceShape {
+  int rl, nblk_w, nblk_bias;
+};
+inline WgReduceShape wgrad_reduce_shape(int nsplit, int Cin, int Cout, bool with_bias) {
+  const int nout = 9 * Cin * Cout;
+  WgReduceShape r;
+  r.rl = (nsplit <= 16 || nout >= (1 << 18)) ? 1 : (nsplit <= 128 ? 4 : 32);
+  r.nblk_w = cdiv(nout, 1024 / r.rl);
+  r.nblk_bias = with_bias ? cdiv(Cout, 32) : 0;
+  return r;
+}
+
+// The reductions of SEVERAL layers in one launch: layer j owns workgroups [first[j], first[j+1]).
+constexpr int WGRAD_MULTI_MAX = 32;
+struct WgMultiArgs {
+  mis_wgrad_reduce_job job[WGRAD_MULTI_MAX];
+  int first[WGRAD_MULTI_MAX + 1];
+  int rl[WGRAD_MULTI_MAX], nblk_w[WGRAD_MULTI_MAX];
+  int n;
+};
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const WgMultiArgs a) {
+  __shared__ double sm[WGRAD_REDUCE_SMEM];
+  int j = 0;
+  while (j + 1 < a.n && (int)blockIdx.x >= a.first[j + 1]) j++;
+  const mis_wgrad_reduce_job& jb = a.job[j];
+  const int blk = (int)blockIdx.x - a.first[j];
+  if (blk >= a.nblk_w[j]) {
+    reduce_rows_block(jb.bias_rows, jb.n_bias_rows, jb.Cout, jb.Cout, jb.dbias, blk - a.nblk_w[j],
+                      reinterpret_cast<double(*)[33]>(sm));
+    return;
+  }
+  if (a.rl[j] == 1) wgrad_reduce_block<1>(jb.slabs, jb.n_slabs, jb.Cin, jb.Cout, jb.dw, blk, sm);
+  else if (a.rl[j] == 4) wgrad_reduce_block<4>(jb.slabs, jb.n_slabs, jb.Cin, jb.Cout, jb.dw, blk, sm);
+  else wgrad_reduce_block<32>(jb.slabs, jb.n_slabs, jb.Cin, jb.Cout, jb.dw, blk, sm);
 }
 
 struct WgPlan {
@@ -1672,9 +1719,10 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1, 
   return true;
 }
 
+// n_slabs_out: not null = write the slabs only and report their number (the caller reduces them later)
 template <typename T>
 int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, float* dw, const BiasRows& bias,
-              void* workspace, hipStream_t st, int dil) {
+              void* workspace, hipStream_t st, int dil, int* n_slabs_out = nullptr) {
   WgPlan p;
   const int Cin = in.channels();
   if (dil < 1 || dil > 3) {
@@ -1725,18 +1773,17 @@ int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, f
 #undef WG_LAUNCH
 #undef WG_LAUNCH_WS
   MIS_CHECK_LAUNCH("conv3x3_wgrad_mfma_kernel");
-  const int nout = 9 * Cin * Cout;
-  const int nb_bias = bias.dbias ? cdiv(Cout, 32) : 0;
-  if (p.nsplit <= 16 || nout >= (1 << 18)) {
-    const int nb = cdiv(nout, 1024);
-    wgrad_reduce_kernel<1><<<nb + nb_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, nb, bias);
-  } else if (p.nsplit <= 128) {
-    const int nb = cdiv(nout, 256);
-    wgrad_reduce_kernel<4><<<nb + nb_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, nb, bias);
-  } else {
-    const int nb = cdiv(nout, 32);
-    wgrad_reduce_kernel<32><<<nb + nb_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, nb, bias);
+  if (n_slabs_out) {
+    *n_slabs_out = p.nsplit;
+    return MIS_OK;
   }
+  const WgReduceShape r = wgrad_reduce_shape(p.nsplit, Cin, Cout, bias.dbias != nullptr);
+  if (r.rl == 1)
+    wgrad_reduce_kernel<1><<<r.nblk_w + r.nblk_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, r.nblk_w, bias);
+  else if (r.rl == 4)
+    wgrad_reduce_kernel<4><<<r.nblk_w + r.nblk_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, r.nblk_w, bias);
+  else
+    wgrad_reduce_kernel<32><<<r.nblk_w + r.nblk_bias, 1024, 0, st>>>(slab, p.nsplit, Cin, Cout, dw, r.nblk_w, bias);
   MIS_CHECK_LAUNCH("wgrad_reduce_kernel");
   return MIS_OK;
 }
@@ -1765,6 +1812,34 @@ int conv3x3_wgrad_mfma(const ConvIn& in, const void* dz, int dtype, int B, int H
                        const BiasRows& bias, void* workspace, hipStream_t st, int dil) {
   if (dtype == MIS_BF16) return run_wgrad<bf16>(in, dz, B, H, W, Cout, dw, bias, workspace, st, dil);
   return run_wgrad<float>(in, dz, B, H, W, Cout, dw, bias, workspace, st, dil);
+}
+
+int conv3x3_wgrad_mfma_slabs(const ConvIn& in, const void* dz, int dtype, int B, int H, int W, int Cout, void* slabs,
+                             int* n_slabs, hipStream_t st, int dil) {
+  const BiasRows none{nullptr, 0, nullptr};
+  if (dtype == MIS_BF16) return run_wgrad<bf16>(in, dz, B, H, W, Cout, nullptr, none, slabs, st, dil, n_slabs);
+  return run_wgrad<float>(in, dz, B, H, W, Cout, nullptr, none, slabs, st, dil, n_slabs);
+}
+
+int conv3x3_wgrad_reduce_multi(const mis_wgrad_reduce_job* jobs, int n_jobs, hipStream_t st) {
+  for (int j0 = 0; j0 < n_jobs; j0 += WGRAD_MULTI_MAX) {
+    WgMultiArgs a;
+    a.n = n_jobs - j0 < WGRAD_MULTI_MAX ? n_jobs - j0 : WGRAD_MULTI_MAX;
+    int total = 0;
+    for (int j = 0; j < a.n; j++) {
+      const mis_wgrad_reduce_job& jb = jobs[j0 + j];
+      const WgReduceShape r = wgrad_reduce_shape(jb.n_slabs, jb.Cin, jb.Cout, jb.dbias != nullptr);
+      a.job[j] = jb;
+      a.first[j] = total;
+      a.rl[j] = r.rl;
+      a.nblk_w[j] = r.nblk_w;
+      total += r.nblk_w + r.nblk_bias;
+    }
+    a.first[a.n] = total;
+    wgrad_reduce_multi_kernel<<<total, 1024, 0, st>>>(a);
+    MIS_CHECK_LAUNCH("wgrad_reduce_multi_kernel");
+  }
+  return MIS_OK;
 }
 
 #if MIS_TIMELINE

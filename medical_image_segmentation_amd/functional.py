@@ -327,14 +327,100 @@ def conv3x3_split_raw(x, w_packed, Ca, Cb):
     return za, zb
 
 
-def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None, bias_rows=None, dilation=1):
+# Weight gradients inside a backward pass are needed only when the pass is over (optimizer, gradient
+# exchange, user code after backward()): each layer writes its partial slabs into a buffer of its
+# own and ONE launch at the end of the pass (or when a gradient bucket is about to be read) reduces
+# the slabs of all layers — instead of one 4-10 us reduction launch per layer.
+DEFER_WGRAD_REDUCE = True
+
+
+class _WgradJob(ctypes.Structure):          # mis_wgrad_reduce_job
+    _fields_ = [("slabs", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("bias_rows", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+                ("n_slabs", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int), ("n_bias_rows", ctypes.c_int)]
+
+
+_wgrad_pending = []      # (job fields, tensors kept alive until the reduction has been enqueued)
+
+
+def flush_wgrad_reduces():
+    """Enqueues the pending weight-gradient reductions (one launch).  Runs by itself at the end of
+    every backward pass; call it before reading a weight gradient INSIDE a backward pass (a
+    gradient hook, a bucket copy)."""
+    if not _wgrad_pending:
+        return
+    pending = list(_wgrad_pending)
+    _wgrad_pending.clear()
+    jobs = (_WgradJob * len(pending))()
+    nbytes = 0
+    for j, (f, _keep) in zip(jobs, pending):
+        j.slabs, j.dw, j.bias_rows, j.dbias, j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = f
+        nbytes += 36 * f[5] * f[6] * (f[4] + 1)
+    with _prof("wgrad_reduce_multi", 0, nbytes):
+        call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), len(pending), _stream())
+
+
+def _in_backward_pass():
+    try:
+        return torch._C._current_graph_task_id() != -1
+    except AttributeError:
+        return False
+
+
+def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cout, B, H, W):
+    """The slabs-only launch + a pending reduction job; False if the shape is not taken by the
+    matrix-core kernels (the caller then uses the one-call form)."""
+    Cin = Ca + Cb
+    if not query("mis_conv3x3_wgrad_slabs_supported", _dt(x), B, H, W, Ca, Cb, Cout, dilation):
+        return None
+    slabs = torch.empty(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), dtype=torch.uint8, device=x.device)
+    n_slabs = ctypes.c_int(0)
+    call("mis_conv3x3_wgrad_slabs", x.data_ptr(), _p(x_ss), _p(x2), _p(x2_ss), dz.data_ptr(), _dt(x), B, H, W, Ca, Cb,
+         Cout, dilation, slabs.data_ptr(), ctypes.addressof(n_slabs), _stream())
+    rows, n_rows, dbias = None, 0, None
+    if bias_rows is not None:
+        rows, n_rows = bias_rows
+        dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    if not _wgrad_pending:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_reduces)
+    # The pending entry keeps the MEMORY of dw / dbias alive (their storages), not the tensors: autograd
+    # takes a returned gradient as .grad without copying only while nobody else refers to the tensor.
+    _wgrad_pending.append(((slabs.data_ptr(), dw.data_ptr(), _p(rows), _p(dbias), n_slabs.value, Cin, Cout, n_rows),
+                           (slabs, dw.untyped_storage(), rows, dbias.untyped_storage() if dbias is not None else None)))
+    return dbias if bias_rows is not None else True
+
+
+def can_defer_wgrad(weight, bias=None):
+    """Whether nothing reads the gradient of `weight` (and `bias`) before the backward pass ends: a leaf
+    without a gradient to accumulate into (autograd then stores the returned tensor as .grad without
+    touching its contents) and without hooks — except hooks that flush first (parallel.GradSync marks
+    its parameters)."""
+    for t in (weight, bias):
+        if t is None:
+            continue
+        if not t.is_leaf or t.grad is not None or t._backward_hooks:
+            return False
+        if getattr(t, "_post_accumulate_grad_hooks", None) and not getattr(t, "_mis_flushing_hooks", False):
+            return False
+    return True
+
+
+def conv3x3_wgrad_raw(x, dz, x_ss=None, x2=None, x2_ss=None, bias_rows=None, dilation=1, defer=False):
     """dW of the conv; with `bias_rows` = (rows tensor [n, Cout], n) also dbias = column sums of
-    the rows, reduced inside the same launch.  Returns dw, or (dw, dbias)."""
+    the rows, reduced inside the same launch.  Returns dw, or (dw, dbias).  With `defer` (and inside
+    a backward pass) the reduction is deferred (see DEFER_WGRAD_REDUCE): the returned tensors are
+    complete once flush_wgrad_reduces() has run."""
     B, Ca, H, W = x.shape
     Cb = x2.shape[1] if x2 is not None else 0
     Cin = Ca + Cb
     Cout = dz.shape[1]
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    if defer and DEFER_WGRAD_REDUCE and _in_backward_pass():
+        with _prof("conv3x3_wgrad", 18 * B * H * W * Cin * Cout,
+                   B * H * W * (Cin + Cout) * x.element_size() + 36 * Cin * Cout,
+                   f"{Cin}->{Cout}@{H}x{W}" + (f" d{dilation}" if dilation != 1 else "")):
+            r = _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cout, B, H, W)
+        if r is not None:
+            return dw if bias_rows is None else (dw, r)
     ws = workspace(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), x.device)
     rows, n_rows, dbias = None, 0, None
     if bias_rows is not None:
@@ -478,6 +564,7 @@ class ConvBnReluFn(torch.autograd.Function):
         ctx.save_for_backward(x, x_ss, x2, x2_ss, z, weight, gamma, beta, ss)
         ctx.training = training
         ctx.has_bias = bias is not None
+        ctx.bias_ref = weakref.ref(bias) if bias is not None else None
         ctx.relu, ctx.dilation = bool(relu), int(dilation)
         ctx.mark_non_differentiable(ss)
         return z, ss
@@ -536,9 +623,11 @@ class ConvBnReluFn(torch.autograd.Function):
                 dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
         dw = None
         if rows is not None:
-            dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=dil)
+            dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=dil,
+                                          defer=(ctx.bias_ref is not None and ctx.bias_ref() is not None
+                                                 and can_defer_wgrad(weight, ctx.bias_ref())))
         elif want_dw:
-            dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=dil)
+            dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=dil, defer=can_defer_wgrad(weight))
         return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
@@ -1061,7 +1150,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 dx, _ = conv3x3_raw(dz, wd, None, Cin, False)
             else:
                 dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
-        dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss) if ctx.needs_input_grad[4] else None
+        dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, defer=can_defer_wgrad(weight)) if ctx.needs_input_grad[4] else None
         db = channel_sum_raw(dz) if (ctx.has_bias and ctx.needs_input_grad[5]) else None
         return dx, None, dx2, None, dw, db
 

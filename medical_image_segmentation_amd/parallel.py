@@ -13,6 +13,8 @@ BatchNorm statistics stay rank-local (plain data-parallel semantics): the parity
 "N reference replicas on N batch shards with averaged gradients".
 """
 import torch
+
+from . import functional as F_
 import torch.distributed as dist
 
 
@@ -61,6 +63,9 @@ class GradSync:
         self.ready = [0] * len(self.buckets)
         self.handles = [None] * len(self.buckets)
         self.host = [None] * len(self.buckets)
+        for p in params:
+            # our hook enqueues the pending weight-gradient reductions before it reads a gradient
+            p._mis_flushing_hooks = not getattr(p, "_post_accumulate_grad_hooks", None)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         model._mis_grad_sync = self
         self.model = model
@@ -95,6 +100,7 @@ class GradSync:
 
     def _launch(self, bi):
         b, flat = self.buckets[bi], self.flat[bi]
+        F_.flush_wgrad_reduces()                  # weight gradients of this pass so far: reductions enqueued
         grads = [p.grad.reshape(-1) for p in b]
         lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
         if not any(lo <= g.data_ptr() < hi for g in grads):

@@ -122,6 +122,7 @@ def clip_and_step(optimizer, params, max_norm=1.0):
     """clip_grad_norm_(params, max_norm) + optimizer.step().  Returns the total gradient norm (a
     0-dim tensor), like clip_grad_norm_."""
     params = [p for p in params]
+    F_.flush_wgrad_reduces()       # (a no-op after a finished backward pass)
     fast = _fast_path(optimizer, params)
     if fast is not None:
         return _launch(optimizer, fast, max_norm)

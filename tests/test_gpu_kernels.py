@@ -562,6 +562,51 @@ def test_conv3x3_wgrad_mfma_vs_direct_and_oracle(F_, dtype, shape, lazy):
     assert rel_err(outs[0], outs[1]) < tol
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_slabs_and_multi_layer_reduce(F_, dtype):
+    """mis_conv3x3_wgrad_slabs + ONE mis_wgrad_reduce_multi over several layers (plain, lazy, two-tensor,
+    dilated, with the conv-bias rows as rider) against the one-call entry points: bit-identical."""
+    import ctypes
+    from medical_image_segmentation_amd import _lib
+    cases = [  # B, Ca, Cb, Cout, H, W, dilation, lazy, bias rows
+        (2, 8, 0, 32, 16, 32, 1, False, 0), (1, 64, 0, 32, 40, 96, 1, True, 7), (1, 64, 0, 256, 16, 16, 1, False, 0),
+        (2, 32, 32, 8, 20, 12, 1, True, 5), (1, 32, 0, 32, 24, 24, 2, False, 3), (1, 16, 0, 64, 18, 34, 3, True, 0),
+        (1, 256, 0, 512, 8, 8, 1, False, 40)]
+    st = torch.cuda.current_stream().cuda_stream
+    code = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    cases = [c for c in cases if _lib.query("mis_conv3x3_wgrad_slabs_supported", code, c[0], c[4], c[5], c[1], c[2], c[3], c[6])]
+    assert len(cases) >= 4
+    jobs = (F_._WgradJob * len(cases))()
+    keep, want = [], []
+    for k, (B, Ca, Cb, Co, H, W, dil, lazy, nr) in enumerate(cases):
+        Ci = Ca + Cb
+        xa = act(dg.hash_normalish((B, Ca, H, W), 1200 + k), dtype)
+        xb = act(dg.hash_normalish((B, Cb, H, W), 1300 + k), dtype) if Cb else None
+        gz = act(dg.hash_normalish((B, Co, H, W), 1400 + k), dtype)
+        ssa = lazy_pair(Ca, 1500 + k).to(DEV) if lazy else None
+        ssb = lazy_pair(Cb, 1600 + k).to(DEV) if (lazy and Cb) else None
+        rows = T(dg.hash_normalish((nr, Co), 1700 + k)).to(DEV) if nr else None
+        ref = F_.conv3x3_wgrad_raw(xa, gz, ssa, xb, ssb, (rows, nr) if nr else None, dilation=dil)
+        want.append(ref if nr else (ref, None))
+        slabs = torch.empty(_lib.query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Ci, Co), dtype=torch.uint8, device=DEV)
+        n = ctypes.c_int(0)
+        _lib.call("mis_conv3x3_wgrad_slabs", xa.data_ptr(), F_._p(ssa), F_._p(xb), F_._p(ssb), gz.data_ptr(), F_._dt(xa),
+                  B, H, W, Ca, Cb, Co, dil, slabs.data_ptr(), ctypes.addressof(n), st)
+        assert n.value >= 1
+        dw = torch.full((Co, Ci, 3, 3), float("nan"), device=DEV)
+        db = torch.full((Co,), float("nan"), device=DEV) if nr else None
+        j = jobs[k]
+        j.slabs, j.dw, j.bias_rows, j.dbias = slabs.data_ptr(), dw.data_ptr(), F_._p(rows), F_._p(db)
+        j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = n.value, Ci, Co, nr
+        keep.append((xa, xb, gz, ssa, ssb, rows, slabs, dw, db))
+    _lib.call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), len(cases), st)
+    torch.cuda.synchronize()
+    for (ref_dw, ref_db), kp in zip(want, keep):
+        assert torch.equal(kp[7], ref_dw)
+        if ref_db is not None:
+            assert torch.equal(kp[8], ref_db)
+
+
 # ---------------------------------------------------------------------------
 # virtual concatenation: conv / data gradient / weight gradient over [xa | xb]
 # ---------------------------------------------------------------------------
