@@ -330,6 +330,14 @@ int mis_bn_relu_bwd_reduce(const void* z, const void* da, int dtype, int64_t n_p
 int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, int C,
                        const float* mean_rstd, const float* gamma, const float* beta, const float* sums,
                        void* dz, float* dbias, void* workspace, mis_stream_t stream);
+/* Pass 2 for the layer whose only consumer is a 1x1 conv (UNet.decoder4 -> out_conv,        */
+/* model/unet.py:82-84): the incoming gradient da is that conv's data gradient, formed on the  */
+/* fly — da[p][c] = sum_j head_dy[p][j] * head_w[j][c], rounded to dtype as mis_conv1x1_bwd      */
+/* stores it (bit-identical results) — instead of being written by mis_conv1x1_bwd (dx = NULL    */
+/* there; its bn_sums are this call's `sums`) and read back here.  head_cout <= 8.               */
+int mis_bn_relu_bwd_dz_head(const void* z, const void* head_dy, const float* head_w, int head_cout, int dtype,
+                            int64_t n_pix, int C, const float* mean_rstd, const float* gamma, const float* beta,
+                            const float* sums, void* dz, float* dbias, void* workspace, mis_stream_t stream);
 /* The same two passes for a BatchNorm2d that is NOT followed by a ReLU of its own  */
 /* (ResDConv's `c1` and `cbr3`, model/utils/modules.py:432-433,444-445): dy is the    */
 /* gradient of the BatchNorm output as it is, no mask.                               */
@@ -353,7 +361,8 @@ size_t mis_conv1x1_bwd_workspace_bytes(int64_t n_pix, int Cin, int Cout);
 /* dx (same dtype), dw float32 [Cout][Cin], dbias float32 [Cout]; dx may be NULL. */
 /* bn_sums (nullable): as for mis_maxpool2x2_bwd — x_affine is then [4][Cin] and   */
 /* float32 [2][Cin] = (sum dy, sum dy*xhat) over (x, dx) is produced in the same    */
-/* pass (dx must be requested).                                                    */
+/* pass (from the values dx holds, or would hold when it is NULL: see               */
+/* mis_bn_relu_bwd_dz_head).                                                       */
 int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int64_t n_pix, int Cin,
                     int Cout, const float* w, void* dx, float* dw, float* dbias, float* bn_sums, void* workspace,
                     mis_stream_t stream);

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "mis_bn_relu_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "mis_bn_relu_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_dz_rows": (_i, [_i, _i64, _i]),
+    "mis_bn_relu_bwd_dz_head": (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -203,18 +203,33 @@ struct ChannelSum {
 // sized so that a thread always works on the same channel vector (grid*256 is a multiple of
 // C/V): it then also accumulates sum(dz) per channel — the conv-bias gradient — from the
 // values it stores, and the block writes one partial row [C].
-template <typename T, int V>
+// HEAD: the incoming gradient `da` is not a tensor but the data gradient of a following 1x1 conv,
+// formed here from that conv's output gradient head_dy [pixel][head_co] and its weights head_w
+// [head_co][C] — da[c] = sum_j dy[j]*w[j][c], rounded to T exactly as the 1x1 backward kernel
+// would have stored it — so that tensor is neither written nor read.
+constexpr int HEAD_MAX_CO = 8;
+template <typename T, int V, bool HEAD = false, int HCO = HEAD_MAX_CO>
 __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __restrict__ z, const T* __restrict__ da,
                                                                     T* __restrict__ dz, int64_t n_vec, int C,
                                                                     float inv_n, const float* __restrict__ mean_rstd,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
                                                                     const float* __restrict__ sums,
-                                                                    float* __restrict__ dz_partials, int relu) {
+                                                                    float* __restrict__ dz_partials, int relu,
+                                                                    const float* __restrict__ head_w = nullptr,
+                                                                    int head_co = 0) {
   extern __shared__ float prm[];   // scratch for the optional bias partial: [256][V]
   const int CV = C / V;
   const int64_t i0 = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   const int c0 = (int)(i0 % CV) * V;
+  // (HCO: compile-time bound of head_co, so the 4-class head keeps 4 weight rows in registers, not 8)
+  float hw[HEAD ? HCO : 1][V];
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int j = 0; j < HCO; j++)
+#pragma unroll
+      for (int k = 0; k < V; k++) hw[j][k] = j < head_co ? head_w[j * C + c0 + k] : 0.f;
+  }
   float mean[V], rstd[V], gam[V], bet[V], m1[V], m2[V];     // this thread's channel constants
 #pragma unroll
   for (int k = 0; k < V; k++) {
@@ -228,10 +243,38 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
   float bsum[V];
 #pragma unroll
   for (int k = 0; k < V; k++) bsum[k] = 0.f;
-  for (int64_t i = i0; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS) {
+  // HEAD: the grid keeps a thread on one channel vector (its stride is a multiple of CV), so the pixel
+  // index advances by a constant: no division in the loop
+  int64_t pix = i0 / CV;
+  const int64_t pix_step = ((int64_t)gridDim.x * EW_THREADS) / CV;
+  for (int64_t i = i0; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS, pix += pix_step) {
     float zv[V], gv[V], o[V];
     vload<T, V>(z + i * V, zv);
-    vload<T, V>(da + i * V, gv);
+    if constexpr (HEAD) {
+      // `da` holds the 1x1 conv's output gradient: head_co values per pixel, one vector load where
+      // the count allows it
+      const T* g_ = da + pix * head_co;
+      float gj[HCO];
+      if (head_co == HCO && (HCO == 4 || HCO == 8)) {
+        vload<T, HCO>(g_, gj);
+      } else {
+#pragma unroll
+        for (int j = 0; j < HCO; j++) gj[j] = j < head_co ? to_f32(g_[j]) : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < V; k++) gv[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < HCO; j++) {
+        if (j < head_co) {
+#pragma unroll
+          for (int k = 0; k < V; k++) gv[k] += gj[j] * hw[j][k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < V; k++) gv[k] = to_f32(from_f32<T>(gv[k]));
+    } else {
+      vload<T, V>(da + i * V, gv);
+    }
 #pragma unroll
     for (int k = 0; k < V; k++) {
       const float xh = (zv[k] - mean[k]) * rstd[k];
@@ -295,16 +338,28 @@ static inline int bwd_dz_grid(int64_t n, int C, int V) {
 template <typename T>
 int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, const float* mean_rstd,
              const float* gamma, const float* beta, const float* sums, float* dbias, void* ws, hipStream_t st,
-             int relu) {
+             int relu, const float* head_w = nullptr, int head_co = 0) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = n_pix * C;
   const size_t lds = (size_t)EW_THREADS * N * sizeof(float);
   const float inv_n = (float)(1.0 / (double)n_pix);
-  const bool vec = pick_vec<T>(C, z, da, dz) == N;
+  const bool vec = (head_w ? pick_vec<T>(C, z, dz) : pick_vec<T>(C, z, da, dz)) == N;
   const int V = vec ? N : 1;
   const int grid = bwd_dz_grid(n, C, V);
   float* partials = dbias ? (float*)ws : nullptr;
-  if (vec)
+  if (head_w && vec && head_co <= 4)
+    bn_relu_bwd_dz_kernel<T, N, true, 4><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n / N, C,
+                                                                          inv_n, mean_rstd, gamma, beta, sums, partials,
+                                                                          relu, head_w, head_co);
+  else if (head_w && vec)
+    bn_relu_bwd_dz_kernel<T, N, true><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n,
+                                                                       mean_rstd, gamma, beta, sums, partials, relu,
+                                                                       head_w, head_co);
+  else if (head_w)
+    bn_relu_bwd_dz_kernel<T, 1, true><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n, C, inv_n,
+                                                                       mean_rstd, gamma, beta, sums, partials, relu,
+                                                                       head_w, head_co);
+  else if (vec)
     bn_relu_bwd_dz_kernel<T, N><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n,
                                                                  mean_rstd, gamma, beta, sums, partials, relu);
   else
@@ -405,7 +460,8 @@ int mis_bn_bwd_reduce(const void* z, const void* dy, int dtype, int64_t n_pix, i
 
 static int bn_bwd_dz_any(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
                          const float* gamma, const float* beta, const float* sums, void* dz, float* dbias,
-                         void* workspace, mis_stream_t stream, int relu) {
+                         void* workspace, mis_stream_t stream, int relu, const float* head_w = nullptr,
+                         int head_co = 0) {
   MIS_REQUIRE(z && da && mean_rstd && gamma && beta && sums && dz, "bn_relu_bwd_dz: null pointer");
   MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_dz: bad shape");
   MIS_REQUIRE(!dbias || workspace, "bn_relu_bwd_dz: dbias requested without a workspace");
@@ -413,9 +469,11 @@ static int bn_bwd_dz_any(const void* z, const void* da, int dtype, int64_t n_pix
                   ((((uintptr_t)z | (uintptr_t)da | (uintptr_t)dz) & 15) == 0),
               "bn_relu_bwd_dz: partial rows need 16-byte aligned tensors");
   if (dtype == MIS_F32)
-    bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream, relu);
+    bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream, relu,
+                    head_w, head_co);
   else if (dtype == MIS_BF16)
-    bwd_dz_t<bf16>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream, relu);
+    bwd_dz_t<bf16>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream, relu,
+                   head_w, head_co);
   else MIS_REQUIRE(false, "bn_relu_bwd_dz: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("bn_relu_bwd_dz_kernel");
   return MIS_OK;
@@ -425,6 +483,15 @@ int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, 
                        const float* gamma, const float* beta, const float* sums, void* dz, float* dbias,
                        void* workspace, mis_stream_t stream) {
   return bn_bwd_dz_any(z, da, dtype, n_pix, C, mean_rstd, gamma, beta, sums, dz, dbias, workspace, stream, 1);
+}
+
+int mis_bn_relu_bwd_dz_head(const void* z, const void* head_dy, const float* head_w, int head_cout, int dtype,
+                            int64_t n_pix, int C, const float* mean_rstd, const float* gamma, const float* beta,
+                            const float* sums, void* dz, float* dbias, void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(head_w && head_cout >= 1 && head_cout <= HEAD_MAX_CO, "bn_relu_bwd_dz_head: 1 <= head_cout <= %d required",
+              HEAD_MAX_CO);
+  return bn_bwd_dz_any(z, head_dy, dtype, n_pix, C, mean_rstd, gamma, beta, sums, dz, dbias, workspace, stream, 1, head_w,
+                       head_cout);
 }
 
 int mis_bn_bwd_dz(const void* z, const void* dy, int dtype, int64_t n_pix, int C, const float* mean_rstd,

@@ -807,7 +807,7 @@ size_t mis_conv1x1_bwd_workspace_bytes(int64_t n_pix, int Cin, int Cout) {
 int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dtype, int64_t n_pix, int Cin, int Cout,
                     const float* w, void* dx, float* dw, float* dbias, float* bn_sums, void* workspace,
                     mis_stream_t stream) {
-  MIS_REQUIRE(!bn_sums || (x_affine && dx), "conv1x1_bwd: bn_sums needs the [4][Cin] affine and dx");
+  MIS_REQUIRE(!bn_sums || x_affine, "conv1x1_bwd: bn_sums needs the [4][Cin] affine");
   MIS_REQUIRE(x && dy && w && dw && dbias && workspace && n_pix >= 1 && Cin >= 1, "conv1x1_bwd: bad arguments");
   MIS_REQUIRE(Cout >= 1 && Cout <= 16, "conv1x1_bwd: 1 <= Cout <= 16 required (got %d)", Cout);
   hipStream_t st = (hipStream_t)stream;

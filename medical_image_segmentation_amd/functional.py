@@ -9,6 +9,7 @@ stored channels-last (`memory_format=torch.channels_last`), dtype float32 or
 bfloat16.  Parameters are float32 in the reference's own layouts.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -507,6 +508,24 @@ def _dgrad_with_bn_sums(dz, wd, x, x_ss):
     return attach_bn_sums(dx, sums, x)
 
 
+class HeadFusion:
+    """Couples a conv+BN+ReLU layer with the 1x1 conv that is the ONLY consumer of its output
+    (UNet.decoder4 -> out_conv, unet.py:82-84): pass one object as `head=` to both Functions.  In the
+    backward pass the 1x1 conv then does not write its data gradient (a full-resolution tensor):
+    it leaves its output gradient and weights here, and the layer's BatchNorm backward forms that
+    gradient on the fly (mis_bn_relu_bwd_dz_head).  The tensor autograd carries between the two
+    nodes is an uninitialised placeholder that must arrive untouched — if the lazy output had
+    another consumer autograd would add to it, and the layer's backward raises."""
+    __slots__ = ("dy", "w", "sums", "ptr", "version")
+
+    def __init__(self):
+        self.dy = self.w = self.sums = None
+        self.ptr = self.version = -1
+
+
+FUSE_HEAD_DZ = os.environ.get("MIS_FUSE_HEAD_DZ", "1") != "0"      # (the environment switch is for A/B timing)
+
+
 class ConvBnReluFn(torch.autograd.Function):
     """(x, x_ss) -> (z, ss): the activation relu(bn(conv(act(x)))) in LAZY form — the conv output z
     plus the BatchNorm affine ss = [scale, shift]; consumers apply relu(z*scale + shift) when they
@@ -515,7 +534,7 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x_ss, x2, x2_ss, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps,
-                momentum, relu=True, dilation=1):
+                momentum, relu=True, dilation=1, head=None):
         """x2 (optional, lazy or plain like x): the input is the virtual concatenation [x | x2].
         relu=False: BatchNorm without a ReLU of its own (ResDConv's `c1` and `cbr3`, modules.py:432-433,
         444-445): ss is then the affine of bn(z) and the incoming gradient is that of the BatchNorm
@@ -566,14 +585,18 @@ class ConvBnReluFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = weakref.ref(bias) if bias is not None else None
         ctx.relu, ctx.dilation = bool(relu), int(dilation)
+        ctx.head = head if (head is not None and relu and FUSE_HEAD_DZ) else None
         ctx.mark_non_differentiable(ss)
         return z, ss
 
     @staticmethod
     def backward(ctx, da, _dss):
         if da is None:
-            return (None,) * 16
+            return (None,) * 17
         x, x_ss, x2, x2_ss, z, weight, gamma, beta, ss = ctx.saved_tensors
+        head = ctx.head if (ctx.head is not None and ctx.head.dy is not None) else None
+        if head is not None and (da.data_ptr() != head.ptr or da._version != head.version):
+            raise RuntimeError("the output of a head-fused conv+BN+ReLU layer had a consumer besides its 1x1 conv")
         mr = ss[2:]
         B, Ca, H, W = x.shape
         Cout, Cin = weight.shape[0], weight.shape[1]
@@ -582,8 +605,11 @@ class ConvBnReluFn(torch.autograd.Function):
         # (sum dy, sum dy*xhat): already produced by the kernel that wrote `da` when that kernel had
         # both z and da in registers (max-pool backward, 1x1-conv backward), else one pass over (z, da)
         relu, dil = ctx.relu, ctx.dilation
-        sums = take_bn_sums(da, z) if relu else None       # (the fused sums carry the ReLU mask)
-        da = to_act(da, x.dtype)
+        if head is not None:
+            sums = head.sums
+        else:
+            sums = take_bn_sums(da, z) if relu else None       # (the fused sums carry the ReLU mask)
+            da = to_act(da, x.dtype)
         ws = workspace(query("mis_bn_relu_bwd_workspace_bytes", n_pix, Cout), x.device)
         if sums is None:
             sums = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
@@ -607,11 +633,19 @@ class ConvBnReluFn(torch.autograd.Function):
             dz_ws = rows
         elif want_db:
             dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
-        with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
-            call("mis_bn_relu_bwd_dz" if relu else "mis_bn_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout,
-                 mr.data_ptr(),
-                 gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
-                 rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
+        if head is not None:
+            hco = head.w.shape[0]
+            with _prof("bn_relu_bwd_dz", 0, (2 * z.numel() + n_pix * hco) * z.element_size()):
+                call("mis_bn_relu_bwd_dz_head", z.data_ptr(), head.dy.data_ptr(), head.w.data_ptr(), hco, _dt(x), n_pix,
+                     Cout, mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
+                     rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
+            head.dy = head.w = head.sums = None
+        else:
+            with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
+                call("mis_bn_relu_bwd_dz" if relu else "mis_bn_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout,
+                     mr.data_ptr(),
+                     gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
+                     rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
         dx = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
             wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
@@ -628,7 +662,7 @@ class ConvBnReluFn(torch.autograd.Function):
                                                  and can_defer_wgrad(weight, ctx.bias_ref())))
         elif want_dw:
             dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=dil, defer=can_defer_wgrad(weight))
-        return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 class MaterializeFn(torch.autograd.Function):
@@ -652,12 +686,14 @@ def materialize(t, ss):
     return t if ss is None else MaterializeFn.apply(t, ss)
 
 
-def conv_bn_relu(x, x_ss, conv, bn, training, x2=None, x2_ss=None):
+def conv_bn_relu(x, x_ss, conv, bn, training, x2=None, x2_ss=None, head=None):
     """(x, x_ss) [| (x2, x2_ss)] -> lazy (z, ss) with the parameters of an nn.Conv2d /
-    nn.BatchNorm2d pair; with x2 the conv input is the virtual concatenation [x | x2]."""
+    nn.BatchNorm2d pair; with x2 the conv input is the virtual concatenation [x | x2].
+    head: a HeadFusion shared with the 1x1 conv that is the only consumer of (z, ss)."""
     momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
     return ConvBnReluFn.apply(x, x_ss, x2, x2_ss, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                              bn.running_var, bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum))
+                              bn.running_var, bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum),
+                              True, 1, head)
 
 
 # ---------------------------------------------------------------------------
@@ -968,10 +1004,13 @@ class Conv1x1Fn(torch.autograd.Function):
     """nn.Conv2d(Cin, n_classes, 1) — unet.py:44,84; the input may be a lazy activation."""
 
     @staticmethod
-    def forward(ctx, x, x_ss, weight, bias):
+    def forward(ctx, x, x_ss, weight, bias, head=None):
         _check_act(x)
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
+        # head: see HeadFusion (needs the batch statistics of a training-mode lazy input, few classes)
+        ctx.head = head if (head is not None and FUSE_HEAD_DZ and x_ss is not None and x_ss.dim() == 2
+                            and x_ss.shape[0] == 4 and Cout <= 8) else None
         y = _empty_act(B, Cout, H, W, x)
         with _prof("conv1x1_fwd", 2 * B * H * W * Cin * Cout, (x.numel() + y.numel()) * x.element_size()):
             call("mis_conv1x1_fwd", x.data_ptr(), _p(x_ss), _dt(x), B * H * W, Cin, Cout, weight.data_ptr(),
@@ -986,19 +1025,26 @@ class Conv1x1Fn(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
         dy = to_act(dy, x.dtype)
+        head = ctx.head if ctx.needs_input_grad[0] else None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
         ws = workspace(query("mis_conv1x1_bwd_workspace_bytes", B * H * W, Cin, Cout), x.device)
         sums = None
-        if dx is not None and _wants_bn_sums(x_ss, x.numel()):
+        if dx is not None and (head is not None or _wants_bn_sums(x_ss, x.numel())):
             sums = torch.empty((2, Cin), dtype=torch.float32, device=x.device)
-        with _prof("conv1x1_bwd", 4 * B * H * W * Cin * Cout, (2 * x.numel() + dy.numel()) * x.element_size()):
+        nbytes = ((1 if head is not None else 2) * x.numel() + dy.numel()) * x.element_size()
+        with _prof("conv1x1_bwd", 4 * B * H * W * Cin * Cout, nbytes):
             call("mis_conv1x1_bwd", x.data_ptr(), _p(x_ss), dy.data_ptr(), _dt(x), B * H * W, Cin, Cout,
-                 weight.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(), _p(sums), ws.data_ptr(), _stream())
-        if sums is not None:
+                 weight.data_ptr(), None if head is not None else _p(dx), dw.data_ptr(), db.data_ptr(), _p(sums),
+                 ws.data_ptr(), _stream())
+        if head is not None:
+            # dx stays uninitialised: the producing layer's backward forms it from (dy, weight)
+            head.dy, head.w, head.sums = dy, weight.detach().reshape(Cout, Cin), sums
+            head.ptr, head.version = dx.data_ptr(), dx._version
+        elif sums is not None:
             attach_bn_sums(dx, sums, x)
-        return dx, None, dw, (db if ctx.has_bias else None)
+        return dx, None, dw, (db if ctx.has_bias else None), None
 
 
 # ---------------------------------------------------------------------------

@@ -75,8 +75,11 @@ class UNet(nn.Module):
         y, sy = self._up(self.decoder1, y, sy, z4, s4, noise(self.bottleneck_dropout, y))
         y, sy = self._up(self.decoder2, y, sy, z3, s3, noise(self.decoder_dropout1, y))
         y, sy = self._up(self.decoder3, y, sy, z2, s2, noise(self.decoder_dropout2, y))
-        y, sy = self._up(self.decoder4, y, sy, z1, s1, None)
-        return F_.Conv1x1Fn.apply(y, sy, self.out_conv.weight, self.out_conv.bias)
+        # decoder4's output has one consumer, the 1x1 head: its gradient is formed inside decoder4's
+        # BatchNorm backward from the head's output gradient and never stored (functional.HeadFusion)
+        head = F_.HeadFusion() if (self.training and torch.is_grad_enabled()) else None
+        y, sy = self._up(self.decoder4, y, sy, z1, s1, None, head)
+        return F_.Conv1x1Fn.apply(y, sy, self.out_conv.weight, self.out_conv.bias, head)
 
     def _pack_weights(self, dtype):
         """All 3x3 conv weights -> the kernels' operand images in one launch (only when a weight
@@ -93,14 +96,14 @@ class UNet(nn.Module):
         packer.refresh()
 
     @staticmethod
-    def _up(block, low, low_ss, skip, skip_ss, low_noise):
+    def _up(block, low, low_ss, skip, skip_ss, low_noise, head=None):
         """x = up(dropout(low)); x = cat([x, skip], 1); x = block(x) — unet.py:64-68.  Where the
         conv kernels take two input tensors the concatenation is virtual: only the upsampled half
         is written, the skip is read in place (lazily) by the conv and its weight gradient, and
         the data gradient comes back as two tensors."""
         if F_.cat_supported(skip, skip, block.cbr1[0].out_channels) and low.shape[1] == skip.shape[1]:
-            return block.forward_lazy(F_.UpsampleFn.apply(low, low_ss, low_noise), None, skip, skip_ss)
-        return block.forward_lazy(F_.UpsampleCatFn.apply(low, low_ss, skip, skip_ss, low_noise))
+            return block.forward_lazy(F_.UpsampleFn.apply(low, low_ss, low_noise), None, skip, skip_ss, head)
+        return block.forward_lazy(F_.UpsampleCatFn.apply(low, low_ss, skip, skip_ss, low_noise), head=head)
 
     def elastic_net(self, l1_lambda, l2_lambda):
         l1_loss = 0

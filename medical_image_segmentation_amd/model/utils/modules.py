@@ -38,12 +38,13 @@ class DoubleConv(nn.Module):
             self.relu)
         self._initialize_weights()
 
-    def forward_lazy(self, x, x_ss=None, x2=None, x2_ss=None):
+    def forward_lazy(self, x, x_ss=None, x2=None, x2_ss=None, head=None):
         """(x, x_ss) [| (x2, x2_ss)] -> (z, ss): both convs read their input through the producer's
         BatchNorm affine + ReLU on load; the block's own output stays lazy (conv output + affine).
-        With x2 the block's input is the channel concatenation [x | x2], never materialised."""
+        With x2 the block's input is the channel concatenation [x | x2], never materialised.
+        head: a functional.HeadFusion, when a 1x1 conv given the same object is the only consumer of (z, ss)."""
         z1, ss1 = F_.conv_bn_relu(x, x_ss, self.cbr1[0], self.cbr1[1], self.training, x2, x2_ss)
-        return F_.conv_bn_relu(z1, ss1, self.cbr2[0], self.cbr2[1], self.training)
+        return F_.conv_bn_relu(z1, ss1, self.cbr2[0], self.cbr2[1], self.training, head=head)
 
     def forward(self, x):
         """x: [B, C, H, W] tensor on the GPU (float32 or bfloat16) -> the block's activation."""
