@@ -68,8 +68,12 @@ def test_amsfn_block_golden(golden):
         assert rel_err(p.grad, ref) < 1e-3, k
 
 
+# measured: 1.5e-4 / 1.1e-3 (aunet_a), 4.5e-3 / 1.4e-2 (aunet_b: one ReLU of a large-gradient pixel flips, as in the U-Net goldens)
+A_UNET_GRAD_NORM_TOL, A_UNET_GRAD_NORM_REL_TOL = 1e-2, 3e-2
+
+
 @pytest.mark.parametrize("name", list(mg.a_unet_cases()))
-def test_a_unet_fp32_golden(golden, name):
+def test_a_unet_fp32_golden(golden, name, report):
     from medical_image_segmentation_amd.model.a_unet import A_UNet
     from medical_image_segmentation_amd.utils.loss_fn import diceloss
     g = golden("a_unet")
@@ -93,11 +97,43 @@ def test_a_unet_fp32_golden(golden, name):
     norms = np.array([float(params[k].grad.double().norm()) for k in keys])
     ref = g[f"{name}.grad_norms"]
     big = ref > 1e-3 * ref.max()
-    assert np.abs(norms[big] - ref[big]).max() / ref.max() < 5e-2
+    dev_abs = float(np.abs(norms[big] - ref[big]).max() / ref.max())
+    dev_rel = float((np.abs(norms[big] - ref[big]) / ref[big]).max())
+    report("fp32 gradient norm deviation / largest norm", dev_abs)
+    report("fp32 gradient norm deviation per tensor (relative, worst)", dev_rel)
+    assert dev_abs < A_UNET_GRAD_NORM_TOL and dev_rel < A_UNET_GRAD_NORM_REL_TOL
     assert rel_err(m.acpn0.final_conv[1].running_mean, g[f"{name}.running_mean.acpn0.final_conv"]) < 1e-3
     m.eval()
     with torch.no_grad():
         assert rel_err(m(x), g[f"{name}.eval_logits"]) < 1e-3
+
+
+def test_a_unet_gradients_with_and_without_fused_bn_sums(golden):
+    """Every AMSFN input has four consumers, so autograd sums their gradients in place into the first one it
+    received; a BatchNorm-sums tag riding on that tensor must then be ignored.  The per-parameter gradients with the
+    fusion on equal those with it off (which uses a reduction pass of its own) within float32 round-off."""
+    from medical_image_segmentation_amd import functional as F_
+    from medical_image_segmentation_amd.model.a_unet import A_UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    g = golden("a_unet")
+    name = "aunet_a"
+    c = mg.a_unet_cases()[name]
+    st = state_from_golden(g, name, c["seed"])
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(DEV)
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)).to(DEV)
+    names = [f"c{i}" for i in range(1, c["ncls"])]
+    F_.BN_SUMS_MIN_NUMEL = 0
+    grads = []
+    for fuse in (True, False):
+        F_.FUSE_BN_SUMS = fuse
+        m = A_UNet(c["cin"], c["ncls"], 0, base_channels=c["base"], compute_dtype=torch.float32)
+        m.load_state_dict(st)
+        m = m.to(DEV).train()
+        diceloss(names)(m(x), t)["total_loss"].backward()
+        grads.append({k: p.grad.double().cpu() for k, p in m.named_parameters()})
+    scale = max(float(v.abs().max()) for v in grads[1].values())
+    for k in grads[0]:
+        assert float((grads[0][k] - grads[1][k]).abs().max()) < 1e-4 * scale, k
 
 
 def test_a_unet_bf16_and_dropout(golden):
