@@ -340,24 +340,25 @@ class _WgradJob(ctypes.Structure):          # mis_wgrad_reduce_job
                 ("n_slabs", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int), ("n_bias_rows", ctypes.c_int)]
 
 
-_wgrad_pending = []      # (job fields, tensors kept alive until the reduction has been enqueued)
+# (device index, stream handle) -> [(job fields, tensors kept alive until the reduction has been enqueued)]:
+# a reduction runs on the device and stream its slabs were written on, whatever is current when it is flushed
+_wgrad_pending = {}
 
 
 def flush_wgrad_reduces():
-    """Enqueues the pending weight-gradient reductions (one launch).  Runs by itself at the end of
-    every backward pass; call it before reading a weight gradient INSIDE a backward pass (a
-    gradient hook, a bucket copy)."""
-    if not _wgrad_pending:
-        return
-    pending = list(_wgrad_pending)
-    _wgrad_pending.clear()
-    jobs = (_WgradJob * len(pending))()
-    nbytes = 0
-    for j, (f, _keep) in zip(jobs, pending):
-        j.slabs, j.dw, j.bias_rows, j.dbias, j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = f
-        nbytes += 36 * f[5] * f[6] * (f[4] + 1)
-    with _prof("wgrad_reduce_multi", 0, nbytes):
-        call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), len(pending), _stream())
+    """Enqueues the pending weight-gradient reductions (one launch per device and stream in use).  Runs by
+    itself at the end of every backward pass; call it before reading a weight gradient INSIDE a
+    backward pass (a gradient hook, a bucket copy)."""
+    while _wgrad_pending:
+        (dev, st), pending = _wgrad_pending.popitem()
+        jobs = (_WgradJob * len(pending))()
+        nbytes = 0
+        for j, (f, _keep) in zip(jobs, pending):
+            j.slabs, j.dw, j.bias_rows, j.dbias, j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = f
+            nbytes += 36 * f[5] * f[6] * (f[4] + 1)
+        with torch.cuda.device(dev):
+            with _prof("wgrad_reduce_multi", 0, nbytes):
+                call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), len(pending), st)
 
 
 def _in_backward_pass():
@@ -375,8 +376,9 @@ def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cou
         return None
     slabs = torch.empty(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), dtype=torch.uint8, device=x.device)
     n_slabs = ctypes.c_int(0)
+    st = _stream()
     call("mis_conv3x3_wgrad_slabs", x.data_ptr(), _p(x_ss), _p(x2), _p(x2_ss), dz.data_ptr(), _dt(x), B, H, W, Ca, Cb,
-         Cout, dilation, slabs.data_ptr(), ctypes.addressof(n_slabs), _stream())
+         Cout, dilation, slabs.data_ptr(), ctypes.addressof(n_slabs), st)
     rows, n_rows, dbias = None, 0, None
     if bias_rows is not None:
         rows, n_rows = bias_rows
@@ -385,8 +387,9 @@ def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cou
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_reduces)
     # The pending entry keeps the MEMORY of dw / dbias alive (their storages), not the tensors: autograd
     # takes a returned gradient as .grad without copying only while nobody else refers to the tensor.
-    _wgrad_pending.append(((slabs.data_ptr(), dw.data_ptr(), _p(rows), _p(dbias), n_slabs.value, Cin, Cout, n_rows),
-                           (slabs, dw.untyped_storage(), rows, dbias.untyped_storage() if dbias is not None else None)))
+    _wgrad_pending.setdefault((x.device.index, st), []).append(
+        ((slabs.data_ptr(), dw.data_ptr(), _p(rows), _p(dbias), n_slabs.value, Cin, Cout, n_rows),
+         (slabs, dw.untyped_storage(), rows, dbias.untyped_storage() if dbias is not None else None)))
     return dbias if bias_rows is not None else True
 
 
