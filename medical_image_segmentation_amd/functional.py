@@ -126,6 +126,9 @@ class _prof:
         return False
 
 
+STREAM_COPY_GBS = 5300.0     # measured: torch.Tensor.copy_ of a large tensor on an MI355X (read + write bytes per second)
+
+
 def profile_summary(peak_hbm_gbs, peak_tflops, steps=1):
     """Per kernel family: time per step, algorithmic GB/s and TFLOP/s, and the roofline
     object of the family with the largest time share."""
@@ -139,9 +142,13 @@ def profile_summary(peak_hbm_gbs, peak_tflops, steps=1):
             if r[4] is not None:            # per-shape lines of the conv families
                 e = layers.setdefault(f"{name} {r[4]}", [0.0, 0, 0, 0])
                 e[0] += t; e[1] += 1; e[2] += r[2]; e[3] += r[3]
+        gbps = by / (ms * 1e-3) / 1e9 if ms > 0 else None
         fams[name] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": len(recs) // steps,
-                      "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                      "GBps": round(gbps, 1) if gbps is not None else None,
                       "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 and fl else None,
+                      # against the HBM peak and against what a plain streaming copy reaches on this part
+                      "frac_of_hbm_peak": round(gbps / peak_hbm_gbs, 3) if gbps is not None else None,
+                      "frac_of_copy_rate": round(gbps / STREAM_COPY_GBS, 3) if gbps is not None else None,
                       "alg_bytes_per_step": by // steps, "alg_flops_per_step": fl // steps}
     per_layer = {}
     for key, (t, n, fl, by) in layers.items():
