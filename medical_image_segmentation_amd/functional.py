@@ -170,6 +170,12 @@ def profile_summary(peak_hbm_gbs, peak_tflops, steps=1):
     else:
         roof = {"bound": "hbm", "achieved": d["GBps"], "peak": peak_hbm_gbs, "unit": "GB/s",
                 "frac": round(d["GBps"] / peak_hbm_gbs, 4)}
+    # the same family with every layer shape against ITS OWN roof (matrix cores for the deep layers, HBM for
+    # the others): sum of the layers' roof times over the sum of their measured times
+    own = [(v["roofline_frac"] * v["us"] * v["launches_per_step"], v["us"] * v["launches_per_step"])
+           for k, v in per_layer.items() if k.startswith(dom + " ")]
+    if own:
+        roof["frac_per_layer_roofs"] = round(sum(a for a, _ in own) / sum(b for _, b in own), 4)
     roof.update({"kernel": dom, "avg_launch_ms": round(d["ms_per_step"] / max(d["launches_per_step"], 1), 4),
                  "launches_per_step": d["launches_per_step"],
                  "algorithmic_bytes_per_launch": d["alg_bytes_per_step"] // max(d["launches_per_step"], 1),
