@@ -16,6 +16,7 @@ Extra objects on the line:
                 bounded sample of the same workload.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -275,6 +276,12 @@ def main():
     for _ in range(args.warmup):
         step()
     pending.clear()
+    # Python's cyclic garbage collector: a full collection of a freshly started interpreter with torch loaded
+    # stops the host for 80-90 ms (measured: tools/cold_steps.py; in the first process on a box it fell on
+    # step 47, i.e. inside a short timed region).  Collect now and move the survivors out of the collector's
+    # sight, as a long-running training job would be past that point anyway.
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -218,6 +218,11 @@ __global__ __launch_bounds__(LM_THREADS) void loss_metrics_kernel(
     if (hist[i]) atomicAdd(&cm[(int64_t)b * C * C + i], (unsigned long long)hist[i]);
 }
 
+__global__ void clear_counts_kernel(unsigned long long* __restrict__ cm, int n, int* __restrict__ status) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) cm[i] = 0ull;
+  if (threadIdx.x == 0) *status = 0;
+}
+
 // Fixed-order reduction of the per-block partials; T_c comes from the integer counts.
 // 1024 threads: value v = tid % VP (VP = 2C rounded up to a power of two) is summed by
 // 1024/VP row lanes (double accumulators), then a tree over the lanes in LDS.
@@ -452,11 +457,10 @@ int mis_loss_metrics_fwd(const void* logits, int dtype, int64_t sb, int64_t sc, 
   float* partials = (float*)workspace;
   unsigned long long* cmw = cm ? (unsigned long long*)cm
                                : (unsigned long long*)((char*)workspace + align256((size_t)nblk * 2 * C * sizeof(float)));
-  if (hipMemsetAsync(cmw, 0, (size_t)B * C * C * sizeof(int64_t), st) != hipSuccess ||
-      hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) {
-    mis_set_error("loss_metrics_fwd: memset failed");
-    return MIS_ERR_LAUNCH;
-  }
+  // (a kernel, not hipMemsetAsync: captured into a HIP graph, the two memsets left a garbage pattern in the
+  // upper halves of the counts on replays after the first, in some processes — and one launch is cheaper)
+  clear_counts_kernel<<<1, 256, 0, st>>>(cmw, B * C * C, status);
+  MIS_CHECK_LAUNCH("clear_counts_kernel");
   if (dtype == MIS_F32) {
     DISPATCH_C(launch_fwd, float, C, logits, sb, sc, sp, target, B, HW, partials, ce_map, cmw, status, st)
   } else {
@@ -482,7 +486,7 @@ int mis_loss_metrics_fwd_static(const void* logits, int dtype, int64_t sb, int64
   void* ws = static_scratch(&rc);
   if (ws == nullptr) return rc;
   // everything the kernels read from the scratch is written earlier in the same call (partial rows by
-  // every workgroup; the count area is cleared by the memset of mis_loss_metrics_fwd), so what the
+  // every workgroup; the count area is cleared at the start of mis_loss_metrics_fwd), so what the
   // previous call left behind is never seen
   return mis_loss_metrics_fwd(logits, dtype, sb, sc, sp, target, B, C, HW, sums, ce_map, cm, status, ws, stream);
 }

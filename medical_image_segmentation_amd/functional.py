@@ -365,6 +365,25 @@ class _WgradJob(ctypes.Structure):          # mis_wgrad_reduce_job
 _wgrad_pending = {}
 
 
+# The slab launches of a backward pass go to a second stream of the device: nothing on the chain of data
+# gradients reads them before the pass ends, so they fill the gaps that chain leaves on the GPU (the
+# launch boundaries of its ~150 dependent kernels, their tails, the few-microsecond reductions between
+# them).  The inputs of a slab launch stay referenced until the reduction is enqueued, and the
+# reduction's stream first waits for the second stream, so the allocator cannot hand their memory out
+# while the second stream still reads it.  Off while kernels are being timed one by one (PROFILE) and
+# under stream capture (a forked branch inside a HIP graph measured slower than the single chain:
+# 4.62 vs 4.52 ms per replayed step).
+WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
+_side_streams = {}         # device index -> torch.cuda.Stream
+
+
+def _side_stream(dev_index):
+    s = _side_streams.get(dev_index)
+    if s is None:
+        s = _side_streams[dev_index] = torch.cuda.Stream(device=dev_index)
+    return s
+
+
 def flush_wgrad_reduces():
     """Enqueues the pending weight-gradient reductions (one launch per device and stream in use).  Runs by
     itself at the end of every backward pass; call it before reading a weight gradient INSIDE a
@@ -373,10 +392,15 @@ def flush_wgrad_reduces():
         (dev, st), pending = _wgrad_pending.popitem()
         jobs = (_WgradJob * len(pending))()
         nbytes = 0
-        for j, (f, _keep) in zip(jobs, pending):
+        main = None
+        for j, (f, keep) in zip(jobs, pending):
             j.slabs, j.dw, j.bias_rows, j.dbias, j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = f
             nbytes += 36 * f[5] * f[6] * (f[4] + 1)
+            if len(keep) > 4:
+                main = keep[4]
         with torch.cuda.device(dev):
+            if main is not None:            # slabs were written on the device's second stream
+                main.wait_stream(_side_stream(dev))
             with _prof("wgrad_reduce_multi", 0, nbytes):
                 call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), len(pending), st)
 
@@ -397,8 +421,16 @@ def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cou
     slabs = torch.empty(query("mis_conv3x3_wgrad_workspace_bytes", B, H, W, Cin, Cout), dtype=torch.uint8, device=x.device)
     n_slabs = ctypes.c_int(0)
     st = _stream()
+    extra = ()
+    launch_st = st
+    if WGRAD_SIDE_STREAM and PROFILE is None and not torch.cuda.is_current_stream_capturing():
+        main = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device.index)
+        side.wait_stream(main)              # x and dz were written on the current stream
+        launch_st = side.cuda_stream
+        extra = (main, x, x_ss, x2, x2_ss, dz)
     call("mis_conv3x3_wgrad_slabs", x.data_ptr(), _p(x_ss), _p(x2), _p(x2_ss), dz.data_ptr(), _dt(x), B, H, W, Ca, Cb,
-         Cout, dilation, slabs.data_ptr(), ctypes.addressof(n_slabs), st)
+         Cout, dilation, slabs.data_ptr(), ctypes.addressof(n_slabs), launch_st)
     rows, n_rows, dbias = None, 0, None
     if bias_rows is not None:
         rows, n_rows = bias_rows
@@ -409,7 +441,7 @@ def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cou
     # takes a returned gradient as .grad without copying only while nobody else refers to the tensor.
     _wgrad_pending.setdefault((x.device.index, st), []).append(
         ((slabs.data_ptr(), dw.data_ptr(), _p(rows), _p(dbias), n_slabs.value, Cin, Cout, n_rows),
-         (slabs, dw.untyped_storage(), rows, dbias.untyped_storage() if dbias is not None else None)))
+         (slabs, dw.untyped_storage(), rows, dbias.untyped_storage() if dbias is not None else None) + extra))
     return dbias if bias_rows is not None else True
 
 
