@@ -1187,16 +1187,15 @@ class DiceLossFn(torch.autograd.Function):
         ctx.kind = kind
         ctx.in_dtype = logits.dtype
         ctx.mark_non_differentiable(cm, status)
-        if ce is None:
-            ce = torch.zeros((), device=lg.device)
-            ctx.has_ce = False
-        else:
-            ctx.has_ce = True
+        ctx.set_materialize_grads(False)      # (no zero tensors for the outputs nobody differentiates)
+        ctx.has_ce = ce is not None
         return losses, ce, cm, status
 
     @staticmethod
     def backward(ctx, dlosses, dce, _dcm, _dstatus):
         lg, tg, sums = ctx.saved_tensors
+        if dlosses is None and dce is None:
+            return None, None, None, None, None, None
         B, Cc, H, W = lg.shape
         _, sb, sc, sp = _logit_strides(lg)
         w = (dlosses if dlosses is not None else torch.zeros(Cc, device=lg.device)).to(torch.float32).contiguous()
