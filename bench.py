@@ -293,6 +293,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss_val = float(ld["total_loss"].detach())
+    if loss_val != loss_val or abs(loss_val) == float("inf"):
+        # a step that produced non-finite numbers did not do the work being measured
+        raise SystemExit(f"bench.py: rank {rank}: the loss after the timed steps is {loss_val}; no value reported")
     # host post-math of the metrics for the timed steps (outside the timed region: the counts
     # were produced inside it)
     from medical_image_segmentation_amd.utils.train_and_eval import _finish_metrics

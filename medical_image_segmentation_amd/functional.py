@@ -373,7 +373,12 @@ _wgrad_pending = {}
 # while the second stream still reads it.  Off while kernels are being timed one by one (PROFILE) and
 # under stream capture (a forked branch inside a HIP graph measured slower than the single chain:
 # 4.62 vs 4.52 ms per replayed step).
-WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
+# OFF unless MIS_WGRAD_STREAM=1: it gains 2 % (3540 -> 3610 images/s on the benchmark step) but about one
+# process in four ends with non-finite parameters within 45 steps, on the default stream and on a
+# stream of its own, with either kernel form; with every slab launch followed by a wait of the pass's
+# stream (no overlap) 10 of 10 processes were clean, and the kernels do not depend on LDS leftovers
+# (tools/lds_pollution_check.py).  The hazard between the two streams is not found yet.
+WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "0") == "1"
 _side_streams = {}         # device index -> torch.cuda.Stream
 
 
