@@ -377,7 +377,11 @@ _wgrad_pending = {}
 # process in four ends with non-finite parameters within 45 steps, on the default stream and on a
 # stream of its own, with either kernel form; with every slab launch followed by a wait of the pass's
 # stream (no overlap) 10 of 10 processes were clean, and the kernels do not depend on LDS leftovers
-# (tools/lds_pollution_check.py).  The hazard between the two streams is not found yet.
+# (tools/lds_pollution_check.py).  Narrowed down so far: with only the two-tensor-input layer at 512x512
+# (decoder4's first conv, the longest slab kernel) on the second stream every process of 100 steps
+# failed, with all other layers there none did; and a loop that synchronises after every step and
+# compares the gradients of both modes bit for bit (tools/side_stream_check.py) found no difference in
+# 80 steps — the failure needs the host running ahead of the GPU.  Cause not found yet.
 WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "0") == "1"
 _side_streams = {}         # device index -> torch.cuda.Stream
 
