@@ -377,11 +377,22 @@ _wgrad_pending = {}
 # process in four ends with non-finite parameters within 45 steps, on the default stream and on a
 # stream of its own, with either kernel form; with every slab launch followed by a wait of the pass's
 # stream (no overlap) 10 of 10 processes were clean, and the kernels do not depend on LDS leftovers
-# (tools/lds_pollution_check.py).  Narrowed down so far: with only the two-tensor-input layer at 512x512
-# (decoder4's first conv, the longest slab kernel) on the second stream every process of 100 steps
-# failed, with all other layers there none did; and a loop that synchronises after every step and
-# compares the gradients of both modes bit for bit (tools/side_stream_check.py) found no difference in
-# 80 steps — the failure needs the host running ahead of the GPU.  Cause not found yet.
+# (tools/lds_pollution_check.py).  What is known (bench loop, 100 steps, every case 6-12 processes):
+#  * only decoder4's first conv (two-tensor input, 64 -> 8 channels at 512x512, the longest slab kernel)
+#    on the second stream: every process fails; all layers but that one: none fails;
+#  * at the first bad step the gradients of decoder4, of decoder3's second conv and decoder3.cbr1's BatchNorm
+#    bias are fine and decoder3.cbr1's BatchNorm weight gradient is NaN, with everything upstream of it:
+#    the sum of dy*xhat that decoder3's second data-gradient conv forms (mis_conv3x3_dgrad_bn_sums) while
+#    the slab kernel runs beside it — a kernel on the stream of the pass goes wrong, not the slabs;
+#  * the slab kernel reading private copies of its inputs: fails; the same kernel on the second stream on
+#    private copies with its result unused, the real one on the pass's stream: clean; an unrelated
+#    streaming kernel of 0.6 ms on the second stream: clean; a host-side wait for the second stream
+#    before the reduction, or a device synchronisation before the optimizer or at the start of every step:
+#    still fails — ordering between the streams is not the cause;
+#  * extra allocations between backward and the optimizer (finiteness checks) made it disappear, and so
+#    did computing the gradients in both modes per step with a synchronisation (tools/side_stream_check.py).
+# The data-gradient variants that run beside it spill 36-60 bytes per lane to scratch memory; whether
+# that is the link is not established.
 WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "0") == "1"
 _side_streams = {}         # device index -> torch.cuda.Stream
 
