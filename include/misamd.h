@@ -150,6 +150,15 @@ int mis_upsample2x_cat_fwd(const void* low, const float* low_affine, const float
 int mis_upsample2x_cat_bwd(const void* dout, const float* low_noise, int dtype, int B, int h, int w, int Cup, int Cskip,
                            void* dlow, void* dskip, mis_stream_t stream);
 
+/* The multipliers of one nn.Dropout2d call (model/unet.py:49-74: F.dropout2d draws one     */
+/* Bernoulli(1-p) per (sample, channel) and scales the kept maps by 1/(1-p)) from a           */
+/* counter-based generator instead of a generator with state: noise[b*C + c] = 1/(1-p) when    */
+/* the top 24 bits of word 0 of Philox4x32-10(counter = (b*C + c, 0, offset_lo, offset_hi),    */
+/* key = (seed_lo, seed_hi)), as a fraction of 2^24, are below 1-p, else 0.  float32 [B][C],   */
+/* consumed by the `noise` / `low_noise` arguments above.  The caller advances `offset` per    */
+/* call; equal (seed, offset, b, c) give equal values on every device and launch shape.        */
+int mis_dropout2d_noise(uint64_t seed, uint64_t offset, int B, int C, float p, float* noise, mis_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* DoubleConv building block: Conv2d(3x3, pad 1, bias) -> BatchNorm2d -> ReLU   */
 /* (model/utils/modules.py:86-94,97-99).                                        */

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "mis_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mis_upsample2x_cat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_upsample2x_cat_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mis_dropout2d_noise": (_i, [C.c_uint64, C.c_uint64, _i, _i, _f, _vp, _vp]),
     "mis_conv3x3_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mis_pack_conv3x3_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mis_set_conv_path": (_i, [_i]),

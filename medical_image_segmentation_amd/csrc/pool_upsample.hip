@@ -627,6 +627,39 @@ int upcat_bwd(const void* dout, void* dlow, void* dskip, int B, int h, int w, in
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// nn.Dropout2d multipliers from a counter-based generator (Philox4x32-10, Salmon et al. 2011):
+// element i = b*C + c of call `offset` under `seed` is word 0 of philox(counter = (i, 0, offset_lo,
+// offset_hi), key = (seed_lo, seed_hi)); kept when its top 24 bits, as a fraction, are below 1-p.
+// No state and no order: the value of an element depends on (seed, offset, b, c) only, whatever
+// the launch shape, so a captured graph or a second rank can reproduce it.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned philox4x32_10_word0(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                                        unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
+__global__ void dropout2d_noise_kernel(unsigned long long seed, unsigned long long offset, int n, float keep,
+                                       float scale, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned w = philox4x32_10_word0((unsigned)i, 0u, (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed,
+                                         (unsigned)(seed >> 32));
+  const float u = (float)(w >> 8) * (1.0f / 16777216.0f);       // [0, 1) in steps of 2^-24, exact
+  out[i] = u < keep ? scale : 0.f;
+}
+
 extern "C" {
 
 int mis_maxpool2x2_fwd(const void* x, const float* x_affine, const float* noise, int dtype, int B, int H, int W, int C,
@@ -684,6 +717,17 @@ int mis_upsample2x_cat_bwd(const void* dout, const float* low_noise, int dtype, 
   else if (dtype == MIS_BF16) upcat_bwd<bf16>(dout, dlow, dskip, B, h, w, Cup, Cskip, low_noise, (hipStream_t)stream);
   else MIS_REQUIRE(false, "upsample2x_cat_bwd: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("up_bwd_tiled_kernel");
+  return MIS_OK;
+}
+
+int mis_dropout2d_noise(uint64_t seed, uint64_t offset, int B, int C, float p, float* noise, mis_stream_t stream) {
+  MIS_REQUIRE(noise, "dropout2d_noise: null pointer");
+  MIS_REQUIRE(B >= 1 && C >= 1 && (int64_t)B * C < ((int64_t)1 << 31), "dropout2d_noise: bad shape");
+  MIS_REQUIRE(p >= 0.f && p <= 1.f, "dropout2d_noise: p = %g is not a probability", (double)p);
+  const int n = B * C;
+  const float keep = 1.f - p, scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  dropout2d_noise_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(seed, offset, n, keep, scale, noise);
+  MIS_CHECK_LAUNCH("dropout2d_noise_kernel");
   return MIS_OK;
 }
 

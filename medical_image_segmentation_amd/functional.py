@@ -794,7 +794,32 @@ def dropout2d_noise(layer, x):
     B, Cc = x.shape[0], x.shape[1]
     if p >= 1.0:
         return torch.zeros((B, Cc, 1, 1), dtype=torch.float32, device=x.device)
+    if DROPOUT_RNG == "philox":
+        return dropout2d_noise_philox(B, Cc, p, x.device)
     return torch.empty((B, Cc, 1, 1), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
+# "torch": the multipliers come from torch's generator exactly as nn.Dropout2d draws them (same seed ->
+# the same dropped maps as the reference's module on this device).  "philox": from the library's
+# counter-based generator (mis_dropout2d_noise): one launch instead of two, and the value of an element
+# depends only on (seed, offset, sample, channel).
+DROPOUT_RNG = os.environ.get("MIS_DROPOUT_RNG", "torch")
+
+
+def dropout2d_noise_philox(B, Cc, p, device, seed=None, offset=None):
+    """float32 [B, C, 1, 1] multipliers of one Dropout2d call from the counter-based generator.  Without
+    explicit (seed, offset) they are taken from the device's torch generator: its seed, and its Philox
+    offset, which is advanced by 4 — so torch.manual_seed reproduces a run and no later torch draw
+    reuses the counter."""
+    if seed is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise NotImplementedError("counter-based Dropout2d inside a captured graph needs an explicit (seed, offset)")
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        seed, offset = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(offset + 4)
+    noise = torch.empty((B, Cc, 1, 1), dtype=torch.float32, device=device)
+    call("mis_dropout2d_noise", seed & 0xFFFFFFFFFFFFFFFF, int(offset), B, Cc, float(p), noise.data_ptr(), _stream())
+    return noise
 
 
 def _check_noise(noise, B, Cc):

@@ -15,6 +15,7 @@ reference checkout) with explicit formulas on torch-CPU / numpy tensors:
   confusion_counts / metrics_update   utils/metrics.py:24-152
   train_step                   utils/train_and_eval.py:63-121 (one batch)
   slide_*                      utils/slide_predict.py:15-117
+  dropout2d_noise_philox       model/unet.py:49-74 (nn.Dropout2d) with a counter-based generator
 
 Parity pinning: the reference ships no tests or golden vectors, so this
 restatement is pinned by outputs of the reference itself, generated in the build
@@ -698,3 +699,39 @@ def slide_blend(class_maps, positions, padded_hw, orig_hw, window):
     fo, fw = output[:oh, :ow], weight[:oh, :ow]
     fo = np.divide(fo, fw, where=fw != 0)
     return np.round(fo).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------
+# Dropout2d multipliers from a counter-based generator (model/unet.py:49-74 applies nn.Dropout2d:
+# one Bernoulli(1-p) per (sample, channel), kept maps scaled by 1/(1-p)).  The reference draws them
+# from torch's generator; the counter-based form has no reference counterpart to pin against, so it
+# is pinned by the published known-answer vectors of Philox4x32-10 (Salmon, Moraes, Dror, Shaw,
+# "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 kat_vectors).
+# ----------------------------------------------------------------------------
+def philox4x32_10(counter, key):
+    """counter: 4 uint32 values (arrays broadcast), key: 2 uint32 values -> 4 uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) for v in counter)
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & m32
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & m32
+        c1, c3, c0, c2 = p1 & m32, p0 & m32, n0, n2
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return tuple(v.astype(np.uint32) for v in (c0, c1, c2, c3))
+
+
+def dropout2d_noise_philox(seed, offset, B, C, p):
+    """float32 [B, C]: 1/(1-p) where the top 24 bits of word 0 of philox(counter=(b*C+c, 0, offset), key=seed),
+    as a fraction of 2**24, are below 1-p, else 0 (float32 comparisons, as the kernel makes them)."""
+    i = np.arange(B * C, dtype=np.uint64)
+    z = np.zeros_like(i)
+    w0 = philox4x32_10((i, z, z + np.uint64(offset & 0xFFFFFFFF), z + np.uint64(offset >> 32)),
+                       (seed & 0xFFFFFFFF, seed >> 32))[0]
+    u = (w0 >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    keep = np.float32(1.0) - np.float32(p)
+    scale = np.float32(1.0) / keep if p < 1.0 else np.float32(0.0)
+    return np.where(u < keep, scale, np.float32(0.0)).astype(np.float32).reshape(B, C)

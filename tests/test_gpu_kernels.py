@@ -940,3 +940,36 @@ def test_dropout_noise_is_torch_feature_dropout(F_):
         assert torch.equal(ref, x * nz)
         assert F_.dropout2d_noise(layer.eval(), x) is None
     assert F_.dropout2d_noise(torch.nn.Dropout2d(0.0).train(), x) is None
+
+
+def test_dropout_noise_counter_based_generator(F_):
+    """mis_dropout2d_noise against the CPU restatement of Philox4x32-10 (pinned by the published
+    known-answer vectors in tests/test_oracle_golden.py): bit-exact multipliers for several (seed, offset,
+    shape, p); an element depends on (seed, offset, b, c) only; the keep rate is 1-p; and through
+    functional.dropout2d_noise the torch seed reproduces a run while successive calls differ."""
+    for seed, offset, B, C, p in [(0, 0, 1, 8, 0.5), (1234, 4, 16, 256, 0.3), ((1 << 63) + 12345, (1 << 40) + 8, 5, 37, 0.03),
+                                  (7, 12, 3, 512, 0.9), (7, 12, 2, 16, 1.0), (7, 12, 2, 16, 0.0)]:
+        nz = F_.dropout2d_noise_philox(B, C, p, DEV, seed=seed, offset=offset)
+        ref = orc.dropout2d_noise_philox(seed, offset, B, C, p)
+        assert nz.shape == (B, C, 1, 1) and nz.dtype == torch.float32
+        assert np.array_equal(nz.cpu().numpy().reshape(B, C), ref), (seed, offset, B, C, p)
+    # the first rows of a larger call are the smaller call (no dependence on the launch shape)
+    a = F_.dropout2d_noise_philox(4, 64, 0.4, DEV, seed=99, offset=0).flatten()
+    b = F_.dropout2d_noise_philox(64, 64, 0.4, DEV, seed=99, offset=0).flatten()
+    assert torch.equal(a, b[:a.numel()])
+    big = F_.dropout2d_noise_philox(64, 1024, 0.3, DEV, seed=5, offset=0)
+    assert abs(float((big > 0).float().mean()) - 0.7) < 0.01
+    assert float(big.max()) == float(np.float32(1.0) / (np.float32(1.0) - np.float32(0.3)))
+    # driven by torch's generator: same seed -> same multipliers, next call -> others
+    F_.DROPOUT_RNG = "philox"
+    try:
+        layer = torch.nn.Dropout2d(0.5).train()
+        x = torch.ones(8, 128, 2, 2, device=DEV)
+        torch.manual_seed(321)
+        n1, n2 = F_.dropout2d_noise(layer, x), F_.dropout2d_noise(layer, x)
+        torch.manual_seed(321)
+        m1 = F_.dropout2d_noise(layer, x)
+        assert torch.equal(n1, m1) and not torch.equal(n1, n2)
+        assert F_.dropout2d_noise(layer.eval(), x) is None
+    finally:
+        F_.DROPOUT_RNG = "torch"

@@ -371,3 +371,22 @@ def test_rdam_unet(golden, name):
     close([float(v) for v in ld.values()], g[f"{name}.loss"], 1e-5, 1e-6)
     close(st["encoder3.cbr3.1.running_mean"].numpy(), g[f"{name}.running_mean.encoder3.cbr3"], 1e-4, 1e-6)
     assert rel(orc.rdam_unet_forward(x, st, training=False).numpy(), g[f"{name}.eval_logits"]) < 1e-3
+
+
+def test_philox_known_answer_vectors():
+    """The counter-based generator behind mis_dropout2d_noise: the oracle's Philox4x32-10 against the
+    published known-answer vectors (Random123 kat_vectors, `philox4x32 10` lines), and the shape of the
+    multipliers it derives."""
+    kat = [((0, 0, 0, 0), (0, 0), "6627e8d5 e169c58d bc57ac4c 9b00dbd8"),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, "408f276d 41c83b0e a20bc7c6 6d5451fd"),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            "d16cfe09 94fdcceb 5001e420 24126ea1")]
+    for ctr, key, want in kat:
+        got = " ".join("%08x" % int(v) for v in orc.philox4x32_10(ctr, key))
+        assert got == want
+    nz = orc.dropout2d_noise_philox(1234, 4, 16, 256, 0.3)
+    assert nz.shape == (16, 256) and nz.dtype == np.float32
+    assert set(np.unique(nz)) == {np.float32(0.0), np.float32(1.0) / (np.float32(1.0) - np.float32(0.3))}
+    assert abs(float((nz > 0).mean()) - 0.7) < 0.02
+    assert not np.array_equal(nz, orc.dropout2d_noise_philox(1234, 8, 16, 256, 0.3))
+    assert np.all(orc.dropout2d_noise_philox(1, 0, 2, 8, 1.0) == 0) and np.all(orc.dropout2d_noise_philox(1, 0, 2, 8, 0.0) == 1)
