@@ -390,7 +390,8 @@ _wgrad_pending = {}
 #    before the reduction, or a device synchronisation before the optimizer or at the start of every step:
 #    still fails — ordering between the streams is not the cause;
 #  * extra allocations between backward and the optimizer (finiteness checks) made it disappear, and so
-#    did computing the gradients in both modes per step with a synchronisation (tools/side_stream_check.py).
+#    did computing the gradients in both modes per step with a synchronisation (tools/side_stream_check.py),
+#    and so did device-side NaN probes of that data-gradient launch's inputs and outputs (4 of 4 clean).
 # The data-gradient variants that run beside it spill 36-60 bytes per lane to scratch memory; whether
 # that is the link is not established.
 WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "0") == "1"
