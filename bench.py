@@ -293,9 +293,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss_val = float(ld["total_loss"].detach())
-    if loss_val != loss_val or abs(loss_val) == float("inf"):
+    bad = loss_val != loss_val or abs(loss_val) == float("inf")
+    if dist_on:
+        # every rank leaves together: a rank that went on alone would wait in the next collective for ever
+        flag = torch.tensor([1.0 if bad else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        bad = bool(flag.item() > 0)
+    if bad:
         # a step that produced non-finite numbers did not do the work being measured
-        raise SystemExit(f"bench.py: rank {rank}: the loss after the timed steps is {loss_val}; no value reported")
+        if dist_on:
+            dist.destroy_process_group()
+        raise SystemExit(f"bench.py: rank {rank}: the loss after the timed steps is {loss_val} "
+                         "(or not finite on another rank); no value reported")
     # host post-math of the metrics for the timed steps (outside the timed region: the counts
     # were produced inside it)
     from medical_image_segmentation_amd.utils.train_and_eval import _finish_metrics
