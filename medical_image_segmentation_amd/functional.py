@@ -608,6 +608,11 @@ class HeadFusion:
         self.ptr = self.version = -1
 
 
+# Order of a layer's two backward convs.  Weight gradient first: the data gradient is then the last kernel of the
+# layer, and what consumes its output — the next layer's BatchNorm backward, the upsampling or pooling backward —
+# runs right behind it, while that tensor is still in the memory-side cache (measured 4.50 -> 4.48 ms per step,
+# identical results; MIS_WGRAD_FIRST=0 restores the other order for A/B timing).
+WGRAD_FIRST = os.environ.get("MIS_WGRAD_FIRST", "1") != "0"
 FUSE_HEAD_DZ = os.environ.get("MIS_FUSE_HEAD_DZ", "1") != "0"      # (the environment switch is for A/B timing)
 
 
@@ -732,14 +737,20 @@ class ConvBnReluFn(torch.autograd.Function):
                      gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
                      rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
         dx = dx2 = None
-        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
-            wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
-            if x2 is None:
-                dx = _dgrad_with_bn_sums(dz, wd, x, x_ss) if (FUSE_BN_SUMS and dil == 1) else None
-                if dx is None:
-                    dx, _ = conv3x3_raw(dz, wd, None, Cin, False, dilation=dil)
-            else:
-                dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
+
+        def data_gradient():
+            nonlocal dx, dx2
+            if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[2]):
+                wd = ctx.wt if ctx.wt is not None else pack_weights(weight.detach(), x.dtype, transposed=True)
+                if x2 is None:
+                    dx = _dgrad_with_bn_sums(dz, wd, x, x_ss) if (FUSE_BN_SUMS and dil == 1) else None
+                    if dx is None:
+                        dx, _ = conv3x3_raw(dz, wd, None, Cin, False, dilation=dil)
+                else:
+                    dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
+
+        if not WGRAD_FIRST:
+            data_gradient()
         dw = None
         if rows is not None:
             dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=dil,
@@ -747,6 +758,8 @@ class ConvBnReluFn(torch.autograd.Function):
                                                  and can_defer_wgrad(weight, ctx.bias_ref())))
         elif want_dw:
             dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=dil, defer=can_defer_wgrad(weight))
+        if WGRAD_FIRST:
+            data_gradient()
         return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
