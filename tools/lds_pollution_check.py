@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Do the kernels depend on LDS they never wrote?  Runs train steps of the benchmark model twice from
-the same state: plain, and with a launch that fills every CU's LDS with a NaN bit pattern before every
+"""Do the kernels depend on LDS or vector registers they never wrote?  Runs train steps of the benchmark model twice from
+the same state: plain, and with launches that fill every CU's LDS and every vector register with a NaN bit pattern before every
 library call.  Every reduction is fixed-order, so the two runs must agree bit for bit; a difference names
 the parameters whose gradients changed.   python tools/lds_pollution_check.py [--only substring]"""
 import argparse
@@ -25,6 +25,7 @@ args = ap.parse_args()
 
 pol = ctypes.CDLL(os.path.join(ROOT, "tools", "micro", "libpollute.so"))
 pol.pollute_lds.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
+pol.pollute_regs.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
 F_.WGRAD_SIDE_STREAM = False
 real_call = F_.call
@@ -35,7 +36,9 @@ hit = set()
 
 def call(name, *a):
     if polluting[0] and args.only in name:
-        pol.pollute_lds(pattern, F_._stream())
+        rc = pol.pollute_lds(pattern, F_._stream()) or pol.pollute_regs(F_._stream())
+        if rc:
+            raise RuntimeError(f"polluter launch failed: {rc}")
         hit.add(name)
     return real_call(name, *a)
 
