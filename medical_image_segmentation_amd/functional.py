@@ -392,8 +392,11 @@ _wgrad_pending = {}
 #  * extra allocations between backward and the optimizer (finiteness checks) made it disappear, and so
 #    did computing the gradients in both modes per step with a synchronisation (tools/side_stream_check.py),
 #    and so did device-side NaN probes of that data-gradient launch's inputs and outputs (4 of 4 clean).
-# The data-gradient variants that run beside it spill 36-60 bytes per lane to scratch memory; whether
-# that is the link is not established.
+#  * not register spills (a build whose kernels use no scratch memory fails 3 runs in 10), not leftovers in LDS or
+#    vector registers (tools/lds_pollution_check.py fills both before every launch: bit-identical results), and
+#    the two kernels alone, side by side in a loop outside the model, never differ (tools/pair_stress.py);
+#  * timing: even two or three few-microsecond kernels inserted before or after that data-gradient launch
+#    (allocation-free NaN probes) make the failure disappear.
 WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "0") == "1"
 _side_streams = {}         # device index -> torch.cuda.Stream
 
