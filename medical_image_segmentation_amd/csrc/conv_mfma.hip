@@ -531,9 +531,12 @@ __global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_
             _Pragma("unroll") for (int r = 0; r < 4; r++) zv_[r] = q_.f[r];                              \
           }                                                                                              \
           _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                \
-            const float d_ = (zv_[r] * sc_[r] + sh_[r] > 0.f) ? to_f32(from_f32<T>(acc[m][n][r])) : 0.f; \
+            /* (a select, not a product with zero: where the gradient does not count, nothing that */    \
+            /* was read for it may reach the sums — 0 * NaN is NaN) */                                   \
+            const bool on_ = pvm[m] && cok_ && (zv_[r] * sc_[r] + sh_[r] > 0.f);                         \
+            const float d_ = on_ ? to_f32(from_f32<T>(acc[m][n][r])) : 0.f;                              \
             s1[n][r] += d_;                                                                              \
-            s2[n][r] += d_ * ((zv_[r] - mu_[r]) * rs_[r]);                                               \
+            s2[n][r] += on_ ? d_ * ((zv_[r] - mu_[r]) * rs_[r]) : 0.f;                                   \
           }                                                                                              \
         }                                                                                                \
       }                                                                                                  \
@@ -601,6 +604,13 @@ __global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_
       const int co = n0 * 16 + i % (NT * 16);
       bnt[i] = (co < Cout) ? bn_aff[(i / (NT * 16)) * Cout + co] : 0.f;
     }
+  }
+  if constexpr (BNS && !WS) {
+    // The single-role loop starts with a load-only iteration whose epilogue already reads this table,
+    // before any barrier of the loop: without this one a wave could read entries that another wave has
+    // not written yet, i.e. whatever the LDS held before (harmless only while that is this kernel's
+    // own earlier table; NaNs once another kernel's workgroups use the same CU in between).
+    __syncthreads();
   }
   // Weights that fit one chunk stay in LDS for the whole kernel.  With fewer than 4 groups per
   // position that is always so and they are staged here, once; otherwise (runtime chunk count)

@@ -373,31 +373,16 @@ _wgrad_pending = {}
 # while the second stream still reads it.  Off while kernels are being timed one by one (PROFILE) and
 # under stream capture (a forked branch inside a HIP graph measured slower than the single chain:
 # 4.62 vs 4.52 ms per replayed step).
-# OFF unless MIS_WGRAD_STREAM=1: it gains 2 % (3540 -> 3610 images/s on the benchmark step) but about one
-# process in four ends with non-finite parameters within 45 steps, on the default stream and on a
-# stream of its own, with either kernel form; with every slab launch followed by a wait of the pass's
-# stream (no overlap) 10 of 10 processes were clean, and the kernels do not depend on LDS leftovers
-# (tools/lds_pollution_check.py).  What is known (bench loop, 100 steps, every case 6-12 processes):
-#  * only decoder4's first conv (two-tensor input, 64 -> 8 channels at 512x512, the longest slab kernel)
-#    on the second stream: every process fails; all layers but that one: none fails;
-#  * at the first bad step the gradients of decoder4, of decoder3's second conv and decoder3.cbr1's BatchNorm
-#    bias are fine and decoder3.cbr1's BatchNorm weight gradient is NaN, with everything upstream of it:
-#    the sum of dy*xhat that decoder3's second data-gradient conv forms (mis_conv3x3_dgrad_bn_sums) while
-#    the slab kernel runs beside it — a kernel on the stream of the pass goes wrong, not the slabs;
-#  * the slab kernel reading private copies of its inputs: fails; the same kernel on the second stream on
-#    private copies with its result unused, the real one on the pass's stream: clean; an unrelated
-#    streaming kernel of 0.6 ms on the second stream: clean; a host-side wait for the second stream
-#    before the reduction, or a device synchronisation before the optimizer or at the start of every step:
-#    still fails — ordering between the streams is not the cause;
-#  * extra allocations between backward and the optimizer (finiteness checks) made it disappear, and so
-#    did computing the gradients in both modes per step with a synchronisation (tools/side_stream_check.py),
-#    and so did device-side NaN probes of that data-gradient launch's inputs and outputs (4 of 4 clean).
-#  * not register spills (a build whose kernels use no scratch memory fails 3 runs in 10), not leftovers in LDS or
-#    vector registers (tools/lds_pollution_check.py fills both before every launch: bit-identical results), and
-#    the two kernels alone, side by side in a loop outside the model, never differ (tools/pair_stress.py);
-#  * timing: even two or three few-microsecond kernels inserted before or after that data-gradient launch
-#    (allocation-free NaN probes) make the failure disappear.
-WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "0") == "1"
+# (3540 -> 3610 images/s on the benchmark step; MIS_WGRAD_STREAM=0 switches it off.)  History worth keeping: with
+# this on, one process in four used to end with non-finite parameters.  The cause was not the streams but a kernel
+# of the pass itself: the data-gradient conv with fused BatchNorm sums read its table of (scale, shift, mean, rstd)
+# in a leading load-only iteration BEFORE the first barrier of its loop and multiplied what it read by a zero
+# gradient — harmless while the LDS still held the same table from an earlier workgroup of the same kernel, NaN
+# (0 * NaN) once workgroups of another kernel had used that CU in between, which only happens when two kernels
+# run side by side (a second stream, or a second process on the GPU).  Fixed in csrc/conv_mfma.hip (a barrier
+# after the tables are filled; a select instead of the product); tools/two_procs.sh and tools/repeat_bench.sh
+# reproduce the old failure within seconds on a build without the fix.
+WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
 _side_streams = {}         # device index -> torch.cuda.Stream
 
 

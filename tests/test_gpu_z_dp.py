@@ -147,3 +147,29 @@ def test_two_rank_data_parallel_step_matches_reference_replicas(golden, tmp_path
 def rel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.gpu
+def test_two_processes_on_one_gpu_stay_finite_and_second_stream_is_exact():
+    """Kernels must not depend on what a CU's LDS held before them.  Two independent training processes on one
+    GPU interleave their workgroups on every CU; a table read ahead of its barrier in the data-gradient conv with
+    fused BatchNorm sums used to turn every such pair of runs into NaNs within 150 steps (0 * NaN from another
+    kernel's leftovers).  Also: the weight-gradient slab launches on the second stream give exactly the losses of
+    the single-stream order."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-roofline", "--steps", "60", "--warmup", "3"]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=root) for _ in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, "a process sharing the GPU ended with a non-finite loss"
+        loss = json.loads(o.decode().strip().splitlines()[-1])["final_loss"]
+        assert loss == loss and 0.3 < loss < 0.7
+    losses = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, MIS_WGRAD_STREAM=mode)
+        o = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=root, env=env, timeout=300, check=True).stdout
+        losses[mode] = json.loads(o.decode().strip().splitlines()[-1])["final_loss"]
+    assert losses["0"] == losses["1"], losses
