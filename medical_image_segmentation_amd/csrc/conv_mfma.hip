@@ -536,7 +536,7 @@ __global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_
             const bool on_ = pvm[m] && cok_ && (zv_[r] * sc_[r] + sh_[r] > 0.f);                         \
             const float d_ = on_ ? to_f32(from_f32<T>(acc[m][n][r])) : 0.f;                              \
             s1[n][r] += d_;                                                                              \
-            s2[n][r] += on_ ? d_ * ((zv_[r] - mu_[r]) * rs_[r]) : 0.f;                                   \
+            s2[n][r] = on_ ? __builtin_fmaf(d_, (zv_[r] - mu_[r]) * rs_[r], s2[n][r]) : s2[n][r];        \
           }                                                                                              \
         }                                                                                                \
       }                                                                                                  \
