@@ -383,6 +383,7 @@ _wgrad_pending = {}
 # after the tables are filled; a select instead of the product); tools/two_procs.sh and tools/repeat_bench.sh
 # reproduce the old failure within seconds on a build without the fix.
 WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
+SIDE_STREAM_REDUCES = os.environ.get("MIS_SIDE_REDUCES", "1") != "0"
 _side_streams = {}         # device index -> torch.cuda.Stream
 
 
@@ -402,16 +403,22 @@ def flush_wgrad_reduces():
         jobs = (_WgradJob * len(pending))()
         nbytes = 0
         main = None
-        for j, (f, keep) in zip(jobs, pending):
-            j.slabs, j.dw, j.bias_rows, j.dbias, j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = f
-            nbytes += 36 * f[5] * f[6] * (f[4] + 1)
+        n_jobs = 0
+        for f, keep in pending:
             if len(keep) > 4:
                 main = keep[4]
+            if f is None:                   # reduced on the second stream already, right behind its slabs
+                continue
+            j = jobs[n_jobs]
+            n_jobs += 1
+            j.slabs, j.dw, j.bias_rows, j.dbias, j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = f
+            nbytes += 36 * f[5] * f[6] * (f[4] + 1)
         with torch.cuda.device(dev):
             if main is not None:            # slabs were written on the device's second stream
                 main.wait_stream(_side_stream(dev))
-            with _prof("wgrad_reduce_multi", 0, nbytes):
-                call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), len(pending), st)
+            if n_jobs:
+                with _prof("wgrad_reduce_multi", 0, nbytes):
+                    call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), n_jobs, st)
 
 
 def _in_backward_pass():
@@ -446,10 +453,19 @@ def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cou
         dbias = torch.empty(Cout, dtype=torch.float32, device=x.device)
     if not _wgrad_pending:
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_reduces)
+    fields = (slabs.data_ptr(), dw.data_ptr(), _p(rows), _p(dbias), n_slabs.value, Cin, Cout, n_rows)
+    if extra and SIDE_STREAM_REDUCES:
+        # On the second stream the reduction follows its slabs at once: nothing waits for it there, and what the
+        # stream of the pass meets at the end of the pass is the last layer's reduction instead of all of them.
+        job = (_WgradJob * 1)()
+        j = job[0]
+        j.slabs, j.dw, j.bias_rows, j.dbias, j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = fields
+        call("mis_wgrad_reduce_multi", ctypes.addressof(job), 1, launch_st)
+        fields = None
     # The pending entry keeps the MEMORY of dw / dbias alive (their storages), not the tensors: autograd
     # takes a returned gradient as .grad without copying only while nobody else refers to the tensor.
     _wgrad_pending.setdefault((x.device.index, st), []).append(
-        ((slabs.data_ptr(), dw.data_ptr(), _p(rows), _p(dbias), n_slabs.value, Cin, Cout, n_rows),
+        (fields,
          (slabs, dw.untyped_storage(), rows, dbias.untyped_storage() if dbias is not None else None) + extra))
     return dbias if bias_rows is not None else True
 
