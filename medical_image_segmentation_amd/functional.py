@@ -473,13 +473,27 @@ def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cou
 DEFER_SAME_STREAM = 2        # (truthy) defer the reduction, but keep the slab launch on the stream of the pass
 
 
+def _hw_queues():
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
+
+
+# Parameters with gradient hooks that flush (parallel.GradSync): whether their slab launches go to the second stream
+# as well.  With HIP's default of 4 hardware queues per process the streams of such a run (the pass, the second stream,
+# the collective library's own) share queues and the second stream then costs time instead of saving it (one-rank
+# RCCL group on one GPU: 4.92 vs 4.70 ms per step); with 8 queues it saves as it does without hooks (4.61 vs 4.70).
+# Default: on from 8 queues up (the HIP runtime reads GPU_MAX_HW_QUEUES from the environment when it starts);
+# MIS_DP_SIDE_STREAM=0/1 overrides.
+DP_SIDE_STREAM = (os.environ["MIS_DP_SIDE_STREAM"] != "0") if "MIS_DP_SIDE_STREAM" in os.environ else _hw_queues() >= 8
+
+
 def can_defer_wgrad(weight, bias=None):
     """Whether nothing reads the gradient of `weight` (and `bias`) before the backward pass ends: a leaf
     without a gradient to accumulate into (autograd then stores the returned tensor as .grad without
     touching its contents) and without hooks — except hooks that flush first (parallel.GradSync marks
-    its parameters).  With such hooks the answer is DEFER_SAME_STREAM: the hooks flush in the middle of the
-    pass, and the stream of the pass would wait there for the second stream (measured with a gradient
-    exchange on one GPU: 4.86 ms per step with the slab launches on the second stream, 4.71 without)."""
+    its parameters).  With such hooks the answer is DEFER_SAME_STREAM unless DP_SIDE_STREAM is set (see there)."""
     mode = True
     for t in (weight, bias):
         if t is None:
@@ -489,7 +503,8 @@ def can_defer_wgrad(weight, bias=None):
         if getattr(t, "_post_accumulate_grad_hooks", None):
             if not getattr(t, "_mis_flushing_hooks", False):
                 return False
-            mode = DEFER_SAME_STREAM
+            if not DP_SIDE_STREAM:
+                mode = DEFER_SAME_STREAM
     return mode
 
 
