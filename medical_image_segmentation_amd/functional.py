@@ -394,10 +394,14 @@ def _side_stream(dev_index):
     return s
 
 
-def flush_wgrad_reduces():
+def flush_wgrad_reduces(on_second_stream=False):
     """Enqueues the pending weight-gradient reductions (one launch per device and stream in use).  Runs by
     itself at the end of every backward pass; call it before reading a weight gradient INSIDE a
-    backward pass (a gradient hook, a bucket copy)."""
+    backward pass (a gradient hook, a bucket copy).  on_second_stream: the caller reads the gradients on the
+    device's second stream (current, and already waiting for the stream of the pass): the stream of the pass
+    then waits for nothing here, and the caller owns the returned references — that memory was allocated on the
+    stream of the pass and must stay referenced until that stream has waited for the second one."""
+    held = []
     while _wgrad_pending:
         (dev, st), pending = _wgrad_pending.popitem()
         jobs = (_WgradJob * len(pending))()
@@ -414,11 +418,15 @@ def flush_wgrad_reduces():
             j.slabs, j.dw, j.bias_rows, j.dbias, j.n_slabs, j.Cin, j.Cout, j.n_bias_rows = f
             nbytes += 36 * f[5] * f[6] * (f[4] + 1)
         with torch.cuda.device(dev):
-            if main is not None:            # slabs were written on the device's second stream
+            if on_second_stream:
+                st = _side_stream(dev).cuda_stream
+                held.append(pending)
+            elif main is not None:          # slabs were written on the device's second stream
                 main.wait_stream(_side_stream(dev))
             if n_jobs:
                 with _prof("wgrad_reduce_multi", 0, nbytes):
                     call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), n_jobs, st)
+    return held
 
 
 def _in_backward_pass():

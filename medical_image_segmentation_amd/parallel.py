@@ -12,6 +12,8 @@ latency-bound, hence few large buckets.
 BatchNorm statistics stay rank-local (plain data-parallel semantics): the parity target is
 "N reference replicas on N batch shards with averaged gradients".
 """
+import os
+
 import torch
 
 from . import functional as F_
@@ -69,6 +71,10 @@ class GradSync:
         self.ready = [0] * len(self.buckets)
         self.handles = [None] * len(self.buckets)
         self.host = [None] * len(self.buckets)
+        # (one-rank RCCL group on one MI355X, 8 hardware queues: 4.60 -> 4.49 ms per step, against 4.45 without any
+        # exchange; MIS_DP_LAUNCH_SIDE=0 keeps the bucket work on the stream of the pass)
+        self.launch_on_second_stream = os.environ.get("MIS_DP_LAUNCH_SIDE", "1") != "0"
+        self._held, self._side_used = [], False      # see _launch(): what the second stream still reads
         for p in params:
             # our hook enqueues the pending weight-gradient reductions before it reads a gradient
             p._mis_flushing_hooks = not getattr(p, "_post_accumulate_grad_hooks", None)
@@ -103,10 +109,27 @@ class GradSync:
     def begin_step(self):
         self.ready = [0] * len(self.buckets)
         self.handles = [None] * len(self.buckets)
+        self._held, self._side_used = [], False
 
     def _launch(self, bi):
+        # With the weight-gradient launches on the device's second stream, the bucket is filled and its collective
+        # started from that stream too: it waits for the stream of the pass (the other gradients of the bucket were
+        # written there), and the stream of the pass goes on with backward and meets the result in finish_step().
+        flat = self.flat[bi]
+        if (self.launch_on_second_stream and flat.is_cuda and F_.WGRAD_SIDE_STREAM and F_.DP_SIDE_STREAM
+                and F_.PROFILE is None and not torch.cuda.is_current_stream_capturing()):
+            side = F_._side_stream(flat.device.index)
+            side.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(side):
+                self._launch_on_current(bi, True)
+            self._side_used = True
+        else:
+            self._launch_on_current(bi, False)
+
+    def _launch_on_current(self, bi, on_side):
         b, flat = self.buckets[bi], self.flat[bi]
-        F_.flush_wgrad_reduces()                  # weight gradients of this pass so far: reductions enqueued
+        # weight gradients of this pass so far: reductions enqueued
+        self._held.extend(F_.flush_wgrad_reduces(on_second_stream=on_side))
         views = self.views[bi]
         grads = [p.grad for p in b]
         if not any(g is v for v, g in zip(views, grads)):
@@ -142,6 +165,13 @@ class GradSync:
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)
                 self._launch(bi)
+        if self._side_used:
+            # the buckets were filled on the second stream: the optimizer's stream meets it here, and only then
+            # may the memory that stream read (slabs, saved activations, unreduced gradients) be handed out again
+            dev = self.flat[0].device
+            torch.cuda.current_stream(dev).wait_stream(F_._side_stream(dev.index))
+        self._held, self._side_used = [], False
+        for bi, b in enumerate(self.buckets):
             if self.handles[bi] is not None:
                 self.handles[bi].wait()
             flat = self.flat[bi]

@@ -74,7 +74,8 @@ def test_grad_sync_on_rccl_group_of_one():
             dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_step_matches_reference_replicas(golden, tmp_path):
+@pytest.mark.parametrize("hw_queues", ["4", "8"])
+def test_two_rank_data_parallel_step_matches_reference_replicas(golden, tmp_path, hw_queues):
     """The HIP UNet on two ranks (two processes on cuda:0, gloo group) over the two shards of the
     `dp` golden case: per-rank losses and the exchanged (averaged) gradients against the
     reference's "two replicas, averaged gradients" fixture; then the global-batch mode — Dice sums
@@ -91,7 +92,9 @@ def test_two_rank_data_parallel_step_matches_reference_replicas(golden, tmp_path
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker.py")
-    env = dict(os.environ, MIS_DP_DEBUG="45")        # a hung rank prints its stacks and exits
+    # 8 hardware queues: weight-gradient launches, bucket fills and collectives go through the second stream
+    env = dict(os.environ, MIS_DP_DEBUG="45", GPU_MAX_HW_QUEUES=hw_queues)        # a hung rank prints its stacks and exits
+    env.pop("MIS_DP_SIDE_STREAM", None)
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(tmp_path)], env=env)
              for r in range(2)]
     try:
