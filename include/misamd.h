@@ -181,6 +181,13 @@ int mis_pack_conv3x3_weights_pair(const float* w, int Cout_w, int Cin_w, int dty
 /* Test hook: 0 = pick the kernel per shape (default), 1 = vector-ALU kernels only.   */
 /* Weights must be re-packed after a change.                                          */
 int mis_set_conv_path(int mode);
+/* Test / tuning hook: the number of workgroups the matrix-core conv kernels are launched  */
+/* with.  0 = sized by the library (one round of resident workgroups, the default);        */
+/* n >= 1 = forward / data-gradient launches use n workgroups along the tile axis and the  */
+/* weight gradient n workgroups in all, whatever the shape — the tests use small values so  */
+/* that every persistent workgroup walks many tiles of a small tensor.  Results do not      */
+/* depend on it beyond the summation order of the per-workgroup partial sums.               */
+int mis_set_conv_launch(int fwd_workgroups, int wgrad_workgroups);
 
 /* z = conv3x3(x, w) + bias (bias may be NULL), channels-last, same H,W.        */
 /* If stats is not NULL it receives float32 [2][Cout]: sum z and sum z^2 over   */

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "mis_conv3x3_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mis_pack_conv3x3_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mis_set_conv_path": (_i, [_i]),
+    "mis_set_conv_launch": (_i, [_i, _i]),
     "mis_conv3x3_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "mis_conv3x3_stats_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "mis_pack_conv3x3_job": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),

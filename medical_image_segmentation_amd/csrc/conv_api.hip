@@ -31,6 +31,15 @@ int mis_set_conv_path(int mode) {
   return MIS_OK;
 }
 
+int mis_set_conv_launch(int fwd_workgroups, int wgrad_workgroups) {
+  if (fwd_workgroups < 0 || fwd_workgroups > 8192 || wgrad_workgroups < 0 || wgrad_workgroups > 8192) {
+    mis_set_error("set_conv_launch: workgroup counts must lie in 0..8192 (0 = sized by the library)");
+    return MIS_ERR_ARG;
+  }
+  conv3x3_mfma_set_launch(fwd_workgroups, wgrad_workgroups);
+  return MIS_OK;
+}
+
 size_t mis_conv3x3_packed_weight_bytes(int Cout_w, int Cin_w, int transposed, int dtype) {
   if (Cout_w < 1 || Cin_w < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
   const int Cin = transposed ? Cout_w : Cin_w, Cout = transposed ? Cin_w : Cout_w;

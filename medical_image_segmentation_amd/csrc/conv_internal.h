@@ -36,6 +36,7 @@ struct ConvOut {
 
 // Matrix-core path (conv_mfma.hip).  *_supported tell whether the shape is taken.
 bool conv3x3_mfma_supported(int dtype, int B, int H, int W, int Cin, int Cout);
+void conv3x3_mfma_set_launch(int fwd_workgroups, int wgrad_workgroups);   // 0 = sized by the planners
 bool conv3x3_mfma_cat_supported(int dtype, int Ca, int Cb, int Cout);          // two-tensor input
 bool conv3x3_mfma_split_supported(int dtype, int Cin, int Ca, int Cb);         // two-tensor output
 size_t conv3x3_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);

@@ -904,15 +904,11 @@ int fwd_resident(int NT, int CPG, size_t lds) {
 
 // Largest problem (16x16-pixel tiles) that takes the wave-specialised form: beyond it the layers are
 // bandwidth-bound and several small workgroups per CU keep more bytes in flight than one large one
-// (measured on the 512^2 layers of A_UNet / RDAM_UNet).  MIS_CONV_WS_TILES overrides (tuning).
-inline int ws_max_tiles() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MIS_CONV_WS_TILES");
-    v = e ? atoi(e) : 1024;
-  }
-  return v;
-}
+// (measured on the 512^2 layers of A_UNet / RDAM_UNet).
+constexpr int WS_MAX_TILES = 1024;
+
+// Workgroup counts forced through mis_set_conv_launch (0 = sized by the planners below).
+int g_fwd_workgroups = 0, g_wgrad_workgroups = 0;
 
 // Ca_in: channels of the first input tensor (== Cin for one tensor); Cout_a: channels of the
 // first output tensor (== Cout for one tensor).
@@ -948,14 +944,8 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
     while ((Cout_a / 16) % p.NT != 0) p.NT /= 2;
     if (sizeof(T) == 2 && (Cout - Cout_a) % 8 != 0) p.NT = 1;
   }
-  // MIS_CONV_WS=0 (tuning): never the wave-specialised form
-  static int ws_mode = -1;
-  if (ws_mode < 0) {
-    const char* e = getenv("MIS_CONV_WS");
-    ws_mode = e ? atoi(e) : 1;
-  }
   const int tiles16 = B * ((W + 15) / 16) * ((H + 15) / 16);
-  p.ws = ws_mode != 0 && p.CPG == 4 && p.NT >= 2 && dil == 1 && tiles16 <= ws_max_tiles();
+  p.ws = p.CPG == 4 && p.NT >= 2 && dil == 1 && tiles16 <= WS_MAX_TILES;
   if (!p.ws) {
     // few pixels (the center layers): 64-channel slices would leave one workgroup per CU; 32-channel
     // slices double the workgroups, and two resident per CU hide each other's staging (measured
@@ -973,17 +963,14 @@ bool plan_fwd(int B, int H, int W, int Cin, int Cout, FwdPlan& p, int Ca_in = -1
   if (p.ws && p.lds > 160 * 1024) return false;
   // Total workgroups per launch: as many as are resident at once on 256 CUs, so the persistent
   // workgroups run as one round (a second, partly filled round costs a whole tile range: 10-25 %
-  // on the 128^2 and 256^2 layers).  MIS_CONV_GRID overrides (tuning).
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("MIS_CONV_GRID");
-    forced = e ? atoi(e) : 0;
-  }
+  // on the 128^2 and 256^2 layers).
   // (The 8-channel-input variants stream many tiles per workgroup and measured best at 768 whatever
   // their residency: shorter ranges balance better than one round of long ones.)
-  const int target = forced >= 64 ? forced : p.ws ? 256 : p.CPG == 1 ? 768 : 256 * fwd_resident<T>(p.NT, p.CPG, p.lds);
+  const int target = p.ws ? 256 : p.CPG == 1 ? 768 : 256 * fwd_resident<T>(p.NT, p.CPG, p.lds);
   int gx = target / p.grid_y;
-  if (p.ws) {
+  if (g_fwd_workgroups > 0) {
+    gx = g_fwd_workgroups;                 // mis_set_conv_launch: tests walk many tiles per workgroup
+  } else if (p.ws) {
     // one workgroup per CU, all resident at once: ceil so that no CU is left without one
     gx = (target + p.grid_y - 1) / p.grid_y;
     if (gx < 1) gx = 1;
@@ -1681,13 +1668,7 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1, 
   else if (Cout > 16) { p.cfg = 1; p.CTO = 32; p.CTI = 16; }
   else if (Cin > 16) { p.cfg = 2; p.CTO = 16; p.CTI = 32; }
   else { p.cfg = 0; p.CTO = 16; p.CTI = 16; }
-  // MIS_WGRAD_WS=0 (tuning): never the wave-specialised form
-  static int ws_mode = -1;
-  if (ws_mode < 0) {
-    const char* e = getenv("MIS_WGRAD_WS");
-    ws_mode = e ? atoi(e) : 1;
-  }
-  p.ws = ws_mode != 0 && sizeof(T) == 2 && dil == 1 && p.cfg >= 3;
+  p.ws = sizeof(T) == 2 && dil == 1 && p.cfg >= 3;
   const int TH = wg_tile_h<T>(p.ws, p.CTO, p.CTI);
   if (Ca >= 0 && Ca != Cin && (Ca <= 0 || Ca % p.CTI != 0)) return false;   // channel tiles must not straddle the two inputs
   p.n_co_blocks = (Cout + p.CTO - 1) / p.CTO;
@@ -1701,18 +1682,14 @@ bool plan_wgrad(int B, int H, int W, int Cin, int Cout, WgPlan& p, int Ca = -1, 
   const double act_bytes = (double)B * H * W * (Cin + Cout) * sizeof(T);
   const double dw_bytes = 36.0 * Cin * Cout;
   // one round of resident workgroups on 256 CUs: the four-wave variants fit three per CU, the
-  // 32x32 K-split variant two, the 64x64 block (eight waves) one.  MIS_WGRAD_GRID overrides (tuning).
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("MIS_WGRAD_GRID");
-    forced = e ? atoi(e) : 0;
-  }
-  const int target = forced >= 64 ? forced : (p.cfg == 4 || p.ws) ? 256 : p.cfg == 3 ? 512 : 768;
+  // 32x32 K-split variant two, the 64x64 block (eight waves) one.
+  const int target = (p.cfg == 4 || p.ws) ? 256 : p.cfg == 3 ? 512 : 768;
   int ns = target / nout;
   const int ns_slab = (int)(act_bytes / dw_bytes);
   if (ns > ns_slab) ns = ns_slab;
   const int ns_fill = (256 + nout - 1) / nout;          // at least one workgroup per CU
   if (ns < ns_fill) ns = ns_fill;
+  if (g_wgrad_workgroups > 0) ns = g_wgrad_workgroups / nout;      // mis_set_conv_launch
   if (ns > p.n_tiles) ns = p.n_tiles;
   if (ns > 1024) ns = 1024;
   if (ns < 1) ns = 1;
@@ -1805,11 +1782,22 @@ bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int C
   return dtype == MIS_BF16 ? plan_wgrad<bf16>(B, H, W, Cin, Cout, p) : plan_wgrad<float>(B, H, W, Cin, Cout, p);
 }
 
+// Slab bytes of the largest plan any entry point can run for this shape: the dilated forms are never
+// wave-specialised and may split K further than the plain one.
 size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout) {
-  WgPlan p;
-  const bool ok = dtype == MIS_BF16 ? plan_wgrad<bf16>(B, H, W, Cin, Cout, p) : plan_wgrad<float>(B, H, W, Cin, Cout, p);
-  if (!ok) return 0;
-  return align256((size_t)p.nsplit * 9 * Cin * Cout * sizeof(float));
+  int nsplit = 0;
+  for (int dil = 1; dil <= 3; dil++) {
+    WgPlan p;
+    const bool ok = dtype == MIS_BF16 ? plan_wgrad<bf16>(B, H, W, Cin, Cout, p, -1, dil)
+                                      : plan_wgrad<float>(B, H, W, Cin, Cout, p, -1, dil);
+    if (ok && p.nsplit > nsplit) nsplit = p.nsplit;
+  }
+  return nsplit ? align256((size_t)nsplit * 9 * Cin * Cout * sizeof(float)) : 0;
+}
+
+void conv3x3_mfma_set_launch(int fwd_workgroups, int wgrad_workgroups) {
+  g_fwd_workgroups = fwd_workgroups;
+  g_wgrad_workgroups = wgrad_workgroups;
 }
 
 bool conv3x3_wgrad_mfma_cat_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout) {

@@ -203,6 +203,12 @@ __device__ __forceinline__ void up_taps(int dst, float scale, int n_in, int& i0,
 // affine + ReLU is applied to each of them ONCE (not once per output tap), and they are kept in
 // LDS in the storage type; every output then blends 4 LDS vectors.  `Cdst` is the channel count
 // of the destination pixel (== C, or C + Cskip when the result is the head of a concatenation).
+#ifndef MIS_UP_DEBUG
+#define MIS_UP_DEBUG 0
+#endif
+#if MIS_UP_DEBUG
+__device__ unsigned int up_dbg[8];
+#endif
 constexpr int UP_T = 16;          // output tile edge
 constexpr int UP_SRC = 10;        // max low-res rows/cols under a tile: floor(15*s)+2 with s < 1/2
 
@@ -277,13 +283,73 @@ __global__ __launch_bounds__(EW_THREADS) void up_fwd_tiled_kernel(const T* __res
     up_taps(X, sx, w, x0, x1, wx0, wx1);
     const unsigned char* tb = tile + cv * 16;
     float a[G], bq[G], c[G], d[G], r[G];
-    vload<T, G>(reinterpret_cast<const T*>(tb + ((y0 - ya) * UP_SRC + (x0 - xa)) * PITCH), a);
-    vload<T, G>(reinterpret_cast<const T*>(tb + ((y0 - ya) * UP_SRC + (x1 - xa)) * PITCH), bq);
-    vload<T, G>(reinterpret_cast<const T*>(tb + ((y1 - ya) * UP_SRC + (x0 - xa)) * PITCH), c);
-    vload<T, G>(reinterpret_cast<const T*>(tb + ((y1 - ya) * UP_SRC + (x1 - xa)) * PITCH), d);
+    typedef __attribute__((ext_vector_type(4))) unsigned int raw4;
+    raw4 ra = *reinterpret_cast<const raw4*>(tb + ((y0 - ya) * UP_SRC + (x0 - xa)) * PITCH);
+    raw4 rb = *reinterpret_cast<const raw4*>(tb + ((y0 - ya) * UP_SRC + (x1 - xa)) * PITCH);
+    raw4 rc = *reinterpret_cast<const raw4*>(tb + ((y1 - ya) * UP_SRC + (x0 - xa)) * PITCH);
+    raw4 rd = *reinterpret_cast<const raw4*>(tb + ((y1 - ya) * UP_SRC + (x1 - xa)) * PITCH);
+    vload<T, G>(reinterpret_cast<const T*>(&ra), a);
+    vload<T, G>(reinterpret_cast<const T*>(&rb), bq);
+    vload<T, G>(reinterpret_cast<const T*>(&rc), c);
+    vload<T, G>(reinterpret_cast<const T*>(&rd), d);
 #pragma unroll
     for (int k = 0; k < G; k++) r[k] = hy0 * (wx0 * a[k] + wx1 * bq[k]) + hy1 * (wx0 * c[k] + wx1 * d[k]);
-    vstore<T, G>(out + (((int64_t)b * Ho + Y) * Wo + X) * Cdst + ch, r);
+    T* dstp = out + (((int64_t)b * Ho + Y) * Wo + X) * Cdst + ch;
+    vstore<T, G>(dstp, r);
+#if MIS_UP_DEBUG
+    {
+      // Instrumentation (tools/up_repro.sh, built with -DMIS_UP_DEBUG=1): where does a wrong value come from?
+      // Counters: [0..3] an LDS operand re-read after use differs from the value used; [4] the blended
+      // registers differ from a scalar recomputation; [5] memory differs from the registers; [7] lanes checked.
+      __builtin_amdgcn_sched_barrier(0);
+      raw4 ra2 = *reinterpret_cast<const volatile raw4*>(tb + ((y0 - ya) * UP_SRC + (x0 - xa)) * PITCH);
+      raw4 rb2 = *reinterpret_cast<const volatile raw4*>(tb + ((y0 - ya) * UP_SRC + (x1 - xa)) * PITCH);
+      raw4 rc2 = *reinterpret_cast<const volatile raw4*>(tb + ((y1 - ya) * UP_SRC + (x0 - xa)) * PITCH);
+      raw4 rd2 = *reinterpret_cast<const volatile raw4*>(tb + ((y1 - ya) * UP_SRC + (x1 - xa)) * PITCH);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra2), "+v"(rb2), "+v"(rc2), "+v"(rd2));
+      bool da = false, db = false, dc = false, dd = false;
+      for (int k = 0; k < 4; k++) {
+        da |= ra2[k] != ra[k];
+        db |= rb2[k] != rb[k];
+        dc |= rc2[k] != rc[k];
+        dd |= rd2[k] != rd[k];
+      }
+      if (da) atomicAdd(&up_dbg[0], 1u);
+      if (db) atomicAdd(&up_dbg[1], 1u);
+      if (dc) atomicAdd(&up_dbg[2], 1u);
+      if (dd) atomicAdd(&up_dbg[3], 1u);
+      // the same blend again, one element at a time, from the re-read values
+      float a2[G], b2[G], c2[G], d2[G];
+      vload<T, G>(reinterpret_cast<const T*>(&ra2), a2);
+      vload<T, G>(reinterpret_cast<const T*>(&rb2), b2);
+      vload<T, G>(reinterpret_cast<const T*>(&rc2), c2);
+      vload<T, G>(reinterpret_cast<const T*>(&rd2), d2);
+      union { raw4 u; T t[G]; } want, got;
+      for (int k = 0; k < G; k++) {
+        float top = wx0 * a2[k], bot = wx0 * c2[k];
+        asm volatile("" : "+v"(top), "+v"(bot));
+        top = __builtin_fmaf(wx1, b2[k], top);
+        bot = __builtin_fmaf(wx1, d2[k], bot);
+        asm volatile("" : "+v"(top), "+v"(bot));
+        want.t[k] = from_f32<T>(__builtin_fmaf(hy1, bot, hy0 * top));
+        got.t[k] = from_f32<T>(r[k]);
+      }
+      // values in registers differ by more than rounding?  (compare as floats with a tolerance of 2 bf16 steps)
+      bool dreg = false;
+      for (int k = 0; k < G; k++) {
+        const float w_ = to_f32(want.t[k]), g_ = to_f32(got.t[k]);
+        dreg |= fabsf(w_ - g_) > 0.02f * fmaxf(fabsf(w_), 1e-3f);
+      }
+      if (dreg) atomicAdd(&up_dbg[4], 1u);
+      // what did memory receive?
+      __threadfence();
+      raw4 mem = *reinterpret_cast<const volatile raw4*>(dstp);
+      bool dmem = false;
+      for (int k = 0; k < 4; k++) dmem |= mem[k] != got.u[k];
+      if (dmem) atomicAdd(&up_dbg[5], 1u);
+      atomicAdd(&up_dbg[7], 1u);
+    }
+#endif
   }
 }
 
@@ -732,3 +798,9 @@ int mis_dropout2d_noise(uint64_t seed, uint64_t offset, int B, int C, float p, f
 }
 
 }  // extern "C"
+
+#if MIS_UP_DEBUG
+extern "C" int mis_debug_up_counters(unsigned int* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(up_dbg), sizeof(up_dbg));
+}
+#endif

@@ -419,6 +419,84 @@ def test_full_size_step_properties():
     assert f[2][1] < f[0][1]
 
 
+def test_cfg1_full_size_step_vs_oracle(report):
+    """The reference's own CPU-runnable configuration at its REAL size — UNet(1, 4 classes, base 32),
+    batch 4, 1 x 256 x 256, float32, diceloss, Metrics, clip_grad_norm_(1.0), AdamW(8e-4, wd 1e-4,
+    betas (0.95, 0.999)) (train.py:221-226, utils/train_and_eval.py:63-121) — one training step against
+    the float64 oracle on the same hash-generated batch and weights.  Every conv of the step runs many
+    tiles per workgroup here (1024 tiles per image at full resolution).
+
+    Bounds: logits 1e-5 of their scale, every loss entry 1e-5, Metrics.update bit-equal to the oracle's
+    post-math on the SAME logits (the contract for integer counting) and within a few near-tie pixels of
+    the oracle's own logits, per-tensor gradient norms 5e-3 and elements 3e-2 of the tensor's scale (conv biases under BatchNorm excluded: their
+    gradient is analytically zero), updated weights within 2e-6 except AdamW sign flips of elements whose
+    gradient is round-off."""
+    from medical_image_segmentation_amd.model.unet import UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    from medical_image_segmentation_amd.utils.metrics import Metrics
+    from medical_image_segmentation_amd.utils.optim import clip_and_step
+    B, S, names, lr = 4, 256, ["a", "b", "c"], 8e-4
+    xh = T(dg.hash_normalish((B, 1, S, S), 9100))
+    th = T(dg.blob_mask(B, S, S, 4, 9300))
+    st32 = orc.make_state(1, 4, base=32, seed=91)
+    m = UNet(1, 4, 0, base_channels=32, compute_dtype=torch.float32)
+    m.load_state_dict({k: v.clone() for k, v in st32.items()})
+    m = m.to(DEV).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=lr, betas=(0.95, 0.999), weight_decay=1e-4)
+    logits = m(xh.to(DEV))
+    ld = diceloss(names)(logits, th.to(DEV))
+    met = Metrics(names).update(logits, th.to(DEV))
+    ld["total_loss"].backward()
+    params = dict(m.named_parameters())
+    grads = {k: p.grad.detach().double().cpu() for k, p in params.items()}
+    clip_and_step(opt, list(m.parameters()), 1.0)
+    torch.cuda.synchronize()
+
+    st = {k: v.clone().double() for k, v in st32.items()}
+    ts = orc.TrainState(st)
+    lo = orc.unet_forward(xh.double(), st, training=True)
+    ldo = orc.dice_loss(lo, th, names)
+    ldo["total_loss"].backward()
+    e_logits = rel_err(logits, lo.detach())
+    report("cfg1 256^2 base-32 fp32 logits max error / max |logit|", e_logits)
+    assert e_logits < LOGITS_FP32_TOL
+    got_loss = np.array([float(v.detach()) for v in ld.values()])
+    ref_loss = np.array([float(v.detach()) for v in ldo.values()])
+    report("cfg1 loss max relative error", float(np.max(np.abs(got_loss - ref_loss) / np.abs(ref_loss))))
+    np.testing.assert_allclose(got_loss, ref_loss, rtol=1e-5, atol=1e-7)
+    # metrics: exact on identical logits; the oracle's own logits differ by ~1e-6, which may move a near-tie pixel
+    own = orc.metrics_update(logits.detach().float().cpu(), th, names)
+    assert np.array_equal(met, own)
+    flips = int((logits.detach().argmax(1).cpu() != lo.detach().argmax(1)).sum())
+    report("cfg1 argmax pixels that differ from the oracle's logits (of 262144)", float(flips))
+    assert flips <= 16
+    np.testing.assert_allclose(met, orc.metrics_update(lo.detach().float(), th, names), rtol=0, atol=1e-3)
+    worst, worst_el = (0.0, ""), (0.0, "")
+    for k in ts.keys:
+        if k.endswith(".0.bias") and k != "out_conv.bias":
+            continue
+        a, b = float(grads[k].norm()), float(st[k].grad.norm())
+        worst = max(worst, (abs(a - b) / (b + 1e-12), k))
+        worst_el = max(worst_el, (rel_err(grads[k], st[k].grad), k))
+    report(f"cfg1 gradient norm deviation (worst tensor: {worst[1]})", worst[0])
+    report(f"cfg1 gradient element deviation / max |g| (worst tensor: {worst_el[1]})", worst_el[0])
+    # (a float32 forward differs from the float64 one by ~1e-6, which flips the ReLU of a few pixels whose
+    # pre-activation is that close to zero; where such a pixel carries a large Dice gradient single weight-gradient
+    # elements move by some 1e-3 of the tensor's scale — the norms are the sharp check)
+    assert worst[0] < 5e-3, worst
+    assert worst_el[0] < 3e-2, worst_el
+    # the optimizer step
+    og = [st[k].grad for k in ts.keys]
+    orc.clip_grad_norm(og, 1.0)
+    ts.step = 1
+    orc.adamw_step([st[k] for k in ts.keys], og, ts.m, ts.v, 1, lr=lr)
+    for k in ("out_conv.weight", "center_conv.cbr1.0.weight", "encoder1.cbr1.0.weight", "decoder4.cbr1.1.weight"):
+        d = (params[k].detach().double().cpu() - st[k].detach()).abs()
+        # (the first AdamW step moves every element by lr * g / (|g| + eps'): an element whose clipped gradient is
+        # of the size of its own round-off takes a different step — about 1 % of the center layer's 1.2 M weights)
+        assert float(d.max()) <= 2 * lr + 1e-6 and float((d < 2e-6).double().mean()) > 0.97, (k, float(d.max()))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_deferred_weight_gradient_reduction(dtype):

@@ -97,7 +97,8 @@ def call_probed(name, *a):
             neq = o1 != o2
             if bool(neq.any()):
                 idx = torch.nonzero(neq)
-                _where.append((step_no[0], (B_, h_, w_, Cup_), idx.shape[0], idx[:6].tolist(), idx[-3:].tolist(),
+                vals = [(hex(int(o1[tuple(i)]) & 0xFFFF), hex(int(o2[tuple(i)]) & 0xFFFF)) for i in idx[:24].tolist()]
+                _where.append((step_no[0], (B_, h_, w_, Cup_), idx.shape[0], idx[:24].tolist(), vals, idx[-3:].tolist(),
                                sorted(set(idx[:, 3].tolist()))[:16], sorted(set(idx[:, 0].tolist())),
                                (int(idx[:, 1].min()), int(idx[:, 1].max())), (int(idx[:, 2].min()), int(idx[:, 2].max()))))
         return r
@@ -174,6 +175,14 @@ if os.environ.get("PROBE_UP_TWICE"):
         print(f"pid {os.getpid()}: {what}: launches whose immediate repetition gave another result: {len(pairs)} of {tot}", pairs[:4])
 for w_ in _where:
     print("WHERE", w_)
+try:
+    import ctypes as _c
+    from medical_image_segmentation_amd import _lib as _L
+    cnt = (_c.c_uint * 8)()
+    _L.load().mis_debug_up_counters(cnt)
+    print(f"pid {os.getpid()}: up_dbg counters [lds a, b, c, d re-read differs; registers differ; memory differs; -; lanes]:", list(cnt))
+except AttributeError:
+    pass
 if save_to:
     import json
     json.dump({"labels": [list(map(str, l)) for l in labels], "sums": sums[:len(labels)].cpu().tolist(),
