@@ -28,23 +28,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def _wants_exchange(argv):
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-dist" in argv:
-        return True
-    for i, a in enumerate(argv):
-        if a == "--gpus" and i + 1 < len(argv) and argv[i + 1].isdigit() and int(argv[i + 1]) > 1:
-            return True
-        if a.startswith("--gpus=") and a[7:].isdigit() and int(a[7:]) > 1:
-            return True
-    return False
+def _early_args(argv):
+    """--gpus / --force-dist as argparse reads them, before anything that starts the HIP runtime is imported."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=None)
+    ap.add_argument("--force-dist", action="store_true")
+    return ap.parse_known_args(argv)[0]
 
 
 # Runs with a gradient exchange use three streams side by side (the pass, the weight-gradient stream, the collective
 # library's): with HIP's default of 4 hardware queues per process they share queues and serialise, with 8 they do not
 # (4.92 -> 4.61 ms per step with a one-rank group; functional.DP_SIDE_STREAM).  The HIP runtime reads the variable
-# when it starts, so it is set before anything touches the GPU; MIS_KEEP_HW_QUEUES=1 leaves the environment alone.
-if _wants_exchange(sys.argv[1:]) and os.environ.get("MIS_KEEP_HW_QUEUES") != "1":
+# when it starts, so it is set here, before anything touches the GPU — unless the environment already names a value
+# (that value is used as it is) or a profiler's preloaded library has started the runtime before this line (then the
+# process has the default 4 queues whatever is assigned here: export GPU_MAX_HW_QUEUES=8 ahead of the profiler).
+_early = _early_args(sys.argv[1:])
+_exchange = int(os.environ.get("WORLD_SIZE", "1")) > 1 or (_early.gpus or 1) > 1 or _early.force_dist
+HW_QUEUES_FROM = "environment" if "GPU_MAX_HW_QUEUES" in os.environ else "default"
+if _exchange and HW_QUEUES_FROM == "default" and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    HW_QUEUES_FROM = "bench.py"
 
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -55,7 +58,7 @@ PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (spec)
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node (default: WORLD_SIZE when a launcher set it, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
@@ -78,6 +81,8 @@ def parse():
     ap.add_argument("--global-dice", action="store_true",
                     help="pool the Dice sums over all ranks before the ratio (global-batch loss, one extra 12-float "
                          "all-reduce per step) instead of the per-rank loss of N replicas")
+    ap.add_argument("--dist-timeout", type=int, default=180,
+                    help="seconds a collective (and the rendezvous) may wait for a missing rank before the run fails")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a HIP graph (single GPU; utils/graph_step.py) instead of issuing it "
                          "from Python: same kernels, one host call per step")
@@ -192,13 +197,15 @@ def spawn_ranks(n):
 
 def main():
     args = parse()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+        raise SystemExit(f"--gpus {args.gpus} was given but the launcher set WORLD_SIZE={world}")
     if args.share_gpu:
         if args.backend != "gloo":
             raise SystemExit("--share-gpu needs --backend gloo")
@@ -216,10 +223,13 @@ def main():
         sys.stdout.flush()
         stdout_fd = os.dup(1)
         os.dup2(2, 1)
+        # a rank that never arrives ends the run with an error after the timeout instead of hanging it
+        import datetime
+        limit = datetime.timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
 
     from medical_image_segmentation_amd import _lib, functional as F_
     _lib.load()
@@ -361,7 +371,11 @@ def main():
                        "backend": (("rccl" if args.backend == "nccl" else "gloo") if dist_on else None),
                        "devices": "all ranks on cuda:0 (rehearsal)" if args.share_gpu else "one per rank",
                        "issue": "hip graph replay" if args.graph else "eager",
-                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "ranks_in_group": dist.get_world_size() if dist_on else 1,
+                       "collective_library": (("rccl %s" % ".".join(map(str, torch.cuda.nccl.version()))
+                                               if args.backend == "nccl" else "gloo") if dist_on else None),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (HIP default)"),
+                       "hw_queues_set_by": HW_QUEUES_FROM,
                        "wgrad_stream_with_exchange": bool(F_.DP_SIDE_STREAM) if sync is not None else None},
             "final_loss": round(loss_val, 6),
             "optimizer_table_builds": _optim.PLAN_BUILDS, "optimizer_table_uploads": _optim.PLAN_UPLOADS,

@@ -383,7 +383,6 @@ _wgrad_pending = {}
 # after the tables are filled; a select instead of the product); tools/two_procs.sh and tools/repeat_bench.sh
 # reproduce the old failure within seconds on a build without the fix.
 WGRAD_SIDE_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
-SIDE_STREAM_REDUCES = os.environ.get("MIS_SIDE_REDUCES", "1") != "0"
 _side_streams = {}         # device index -> torch.cuda.Stream
 
 
@@ -462,7 +461,7 @@ def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cou
     if not _wgrad_pending:
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_reduces)
     fields = (slabs.data_ptr(), dw.data_ptr(), _p(rows), _p(dbias), n_slabs.value, Cin, Cout, n_rows)
-    if extra and SIDE_STREAM_REDUCES:
+    if extra:
         # On the second stream the reduction follows its slabs at once: nothing waits for it there, and what the
         # stream of the pass meets at the end of the pass is the last layer's reduction instead of all of them.
         job = (_WgradJob * 1)()
@@ -497,11 +496,22 @@ def _hw_queues():
 DP_SIDE_STREAM = (os.environ["MIS_DP_SIDE_STREAM"] != "0") if "MIS_DP_SIDE_STREAM" in os.environ else _hw_queues() >= 8
 
 
+# Parameters whose gradients are pending in the backward pass `_deferred_pass` (their data pointers).
+_deferred_params = set()
+_deferred_pass = -1
+
+
 def can_defer_wgrad(weight, bias=None):
     """Whether nothing reads the gradient of `weight` (and `bias`) before the backward pass ends: a leaf
     without a gradient to accumulate into (autograd then stores the returned tensor as .grad without
     touching its contents) and without hooks — except hooks that flush first (parallel.GradSync marks
-    its parameters).  With such hooks the answer is DEFER_SAME_STREAM unless DP_SIDE_STREAM is set (see there)."""
+    its parameters).  With such hooks the answer is DEFER_SAME_STREAM unless DP_SIDE_STREAM is set (see there).
+
+    A parameter that feeds SEVERAL conv nodes of one pass (a module called twice, siamese branches,
+    loss(model(x1)) + loss(model(x2))) is deferred once only: autograd adds the gradients the nodes return as soon
+    as the second one arrives, so on a second sighting the pending reductions are enqueued first (the stream of
+    the pass then waits for the second stream) and this node computes its gradient at once."""
+    global _deferred_pass
     mode = True
     for t in (weight, bias):
         if t is None:
@@ -513,6 +523,20 @@ def can_defer_wgrad(weight, bias=None):
                 return False
             if not DP_SIDE_STREAM:
                 mode = DEFER_SAME_STREAM
+    try:
+        task = torch._C._current_graph_task_id()
+    except AttributeError:
+        return False
+    if task == -1:
+        return False
+    if task != _deferred_pass:
+        _deferred_pass = task
+        _deferred_params.clear()
+    keys = [t.data_ptr() for t in (weight, bias) if t is not None]
+    if any(k in _deferred_params for k in keys):
+        flush_wgrad_reduces()
+        return False
+    _deferred_params.update(keys)
     return mode
 
 
@@ -635,12 +659,11 @@ class HeadFusion:
         self.ptr = self.version = -1
 
 
-# Order of a layer's two backward convs.  Weight gradient first: the data gradient is then the last kernel of the
+# Order of a layer's two backward convs: weight gradient first.  The data gradient is then the last kernel of the
 # layer, and what consumes its output — the next layer's BatchNorm backward, the upsampling or pooling backward —
-# runs right behind it, while that tensor is still in the memory-side cache (measured 4.50 -> 4.48 ms per step,
-# identical results; MIS_WGRAD_FIRST=0 restores the other order for A/B timing).
-WGRAD_FIRST = os.environ.get("MIS_WGRAD_FIRST", "1") != "0"
-FUSE_HEAD_DZ = os.environ.get("MIS_FUSE_HEAD_DZ", "1") != "0"      # (the environment switch is for A/B timing)
+# runs right behind it, while that tensor is still in the memory-side cache (measured 4.50 -> 4.48 ms per step
+# against the other order, identical results).
+FUSE_HEAD_DZ = True      # (module attribute: the tests compare the fused and the two-kernel form)
 
 
 class ConvBnReluFn(torch.autograd.Function):
@@ -776,8 +799,7 @@ class ConvBnReluFn(torch.autograd.Function):
                 else:
                     dx, dx2 = conv3x3_split_raw(dz, wd, Ca, Cin - Ca)
 
-        if not WGRAD_FIRST:
-            data_gradient()
+        # weight gradient first, data gradient last: what consumes the data gradient runs right behind it
         dw = None
         if rows is not None:
             dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=dil,
@@ -785,8 +807,7 @@ class ConvBnReluFn(torch.autograd.Function):
                                                  and can_defer_wgrad(weight, ctx.bias_ref())))
         elif want_dw:
             dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=dil, defer=can_defer_wgrad(weight))
-        if WGRAD_FIRST:
-            data_gradient()
+        data_gradient()
         return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 

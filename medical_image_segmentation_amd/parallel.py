@@ -72,8 +72,8 @@ class GradSync:
         self.handles = [None] * len(self.buckets)
         self.host = [None] * len(self.buckets)
         # (one-rank RCCL group on one MI355X, 8 hardware queues: 4.60 -> 4.49 ms per step, against 4.45 without any
-        # exchange; MIS_DP_LAUNCH_SIDE=0 keeps the bucket work on the stream of the pass)
-        self.launch_on_second_stream = os.environ.get("MIS_DP_LAUNCH_SIDE", "1") != "0"
+        # exchange; a test may set this False to keep the bucket work on the stream of the pass)
+        self.launch_on_second_stream = True
         self._held, self._side_used = [], False      # see _launch(): what the second stream still reads
         for p in params:
             # our hook enqueues the pending weight-gradient reductions before it reads a gradient
@@ -116,7 +116,13 @@ class GradSync:
         # started from that stream too: it waits for the stream of the pass (the other gradients of the bucket were
         # written there), and the stream of the pass goes on with backward and meets the result in finish_step().
         flat = self.flat[bi]
-        if (self.launch_on_second_stream and flat.is_cuda and F_.WGRAD_SIDE_STREAM and F_.DP_SIDE_STREAM
+        # (only when slab launches of this pass actually went to the second stream of THIS device: if every layer took
+        # another path, hopping streams would buy a cross-stream wait and nothing else)
+        pending_here = [k for k, v in F_._wgrad_pending.items()
+                        if k[0] == flat.device.index and any(len(keep) > 4 for _f, keep in v)] if flat.is_cuda else []
+        assert all(k[0] == flat.device.index for k in F_._wgrad_pending) or not flat.is_cuda, \
+            "pending weight-gradient reductions of another device: one device per process is the supported layout"
+        if (self.launch_on_second_stream and pending_here and F_.WGRAD_SIDE_STREAM and F_.DP_SIDE_STREAM
                 and F_.PROFILE is None and not torch.cuda.is_current_stream_capturing()):
             side = F_._side_stream(flat.device.index)
             side.wait_stream(torch.cuda.current_stream(flat.device))

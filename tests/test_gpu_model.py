@@ -541,6 +541,47 @@ def test_deferred_weight_gradient_reduction(dtype):
         assert torch.isfinite(got2[k]).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("wgrad_stream", [True, False])
+def test_weights_used_twice_in_one_backward_pass(dtype, wgrad_stream):
+    """loss(model(x1)) + loss(model(x2)) under ONE backward(): every conv weight feeds two nodes of the pass and
+    autograd adds their gradients as soon as the second arrives.  The deferred weight-gradient reduction must then
+    have completed the first one (second stream or not): gradients equal the run with the deferral switched off
+    bit for bit, and equal the sum of two separate passes within float32 round-off."""
+    from medical_image_segmentation_amd import functional as F_
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    c = dict(B=2, cin=1, ncls=3, base=8, hw=32, seed=7)
+    xs = [T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), 4500 + k)).to(DEV) for k in range(2)]
+    ts = [T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], 4600 + k)).to(DEV) for k in range(2)]
+    names = ["a", "b"]
+    saved = F_.WGRAD_SIDE_STREAM
+
+    def grads(defer, together=True):
+        F_.DEFER_WGRAD_REDUCE = defer
+        m = build(c, dtype).eval()             # eval: BatchNorm uses running statistics, so the two calls are independent
+        for p in m.parameters():
+            p.requires_grad_(True)
+        if together:
+            (diceloss(names)(m(xs[0]), ts[0])["total_loss"] + diceloss(names)(m(xs[1]), ts[1])["total_loss"]).backward()
+        else:
+            for x, t in zip(xs, ts):
+                diceloss(names)(m(x), t)["total_loss"].backward()
+        torch.cuda.synchronize()
+        assert not F_._wgrad_pending
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    F_.WGRAD_SIDE_STREAM = wgrad_stream
+    try:
+        ref, got = grads(False), grads(True)
+        sep = grads(False, together=False)
+    finally:
+        F_.WGRAD_SIDE_STREAM = saved
+    for k in ref:
+        assert torch.isfinite(got[k]).all(), k
+        assert torch.equal(ref[k], got[k]), k
+        assert rel_err(got[k], sep[k]) < (1e-5 if dtype == torch.float32 else 2e-2), k
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ncls", [2, 4, 8])

@@ -181,7 +181,7 @@ def test_two_processes_on_one_gpu_stay_finite_and_second_stream_is_exact():
 @pytest.mark.gpu
 def test_exchange_step_with_second_stream_equals_same_stream_order():
     """With a gradient exchange the weight-gradient slabs go to the second stream only when the process has 8
-    hardware queues (bench.py asks for them in runs with an exchange): the losses must be those of the order with
+    hardware queues (bench.py asks for them in runs with an exchange unless the environment names a count): the losses must be those of the order with
     everything on the stream of the pass (4 queues), bit for bit."""
     import json
     import subprocess
@@ -190,11 +190,16 @@ def test_exchange_step_with_second_stream_equals_same_stream_order():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--no-cpu-baseline", "--no-roofline",
            "--steps", "40", "--warmup", "3"]
     seen = {}
-    for keep in ("1", "0"):
-        env = dict(os.environ, MIS_KEEP_HW_QUEUES=keep, GPU_MAX_HW_QUEUES="4", MASTER_PORT=str(29600 + int(keep)))
+    for named in ("4", None):            # the environment names 4 queues / names nothing (bench.py then asks for 8)
+        env = dict(os.environ, MASTER_PORT=str(29600 + (1 if named else 0)))
         env.pop("MIS_DP_SIDE_STREAM", None)
+        env.pop("GPU_MAX_HW_QUEUES", None)
+        if named:
+            env["GPU_MAX_HW_QUEUES"] = named
         o = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=root, env=env, timeout=300, check=True).stdout
-        seen[keep] = json.loads(o.decode().strip().splitlines()[-1])
-    assert seen["1"]["config"]["wgrad_stream_with_exchange"] is False and seen["1"]["config"]["hw_queues"] == "4"
-    assert seen["0"]["config"]["wgrad_stream_with_exchange"] is True and seen["0"]["config"]["hw_queues"] == "8"
-    assert seen["0"]["final_loss"] == seen["1"]["final_loss"], (seen["0"]["final_loss"], seen["1"]["final_loss"])
+        seen[named] = json.loads(o.decode().strip().splitlines()[-1])
+    a, b = seen["4"]["config"], seen[None]["config"]
+    assert a["wgrad_stream_with_exchange"] is False and a["hw_queues"] == "4" and a["hw_queues_set_by"] == "environment"
+    assert b["wgrad_stream_with_exchange"] is True and b["hw_queues"] == "8" and b["hw_queues_set_by"] == "bench.py"
+    assert a["ranks_in_group"] == 1 and a["collective_library"].startswith("rccl")
+    assert seen["4"]["final_loss"] == seen[None]["final_loss"], (seen["4"]["final_loss"], seen[None]["final_loss"])
