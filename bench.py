@@ -37,17 +37,29 @@ def _early_args(argv):
 
 
 # Runs with a gradient exchange use three streams side by side (the pass, the weight-gradient stream, the collective
-# library's): with HIP's default of 4 hardware queues per process they share queues and serialise, with 8 they do not
-# (4.92 -> 4.61 ms per step with a one-rank group; functional.DP_SIDE_STREAM).  The HIP runtime reads the variable
-# when it starts, so it is set here, before anything touches the GPU — unless the environment already names a value
-# (that value is used as it is) or a profiler's preloaded library has started the runtime before this line (then the
-# process has the default 4 queues whatever is assigned here: export GPU_MAX_HW_QUEUES=8 ahead of the profiler).
+# library's): with 4 hardware queues per process (HIP's default, and what the benchmark hosts export) they share queues
+# and serialise, with 8 they do not (4.92 -> 4.61 ms per step with a one-rank group; functional.DP_SIDE_STREAM).  The
+# HIP runtime reads the variable when it starts, so a run with an exchange raises it to 8 here, before anything touches
+# the GPU — unless a profiler's preloaded library has started the runtime before this line: the process then has the
+# queues it was started with whatever is assigned here, so the value is left alone (export GPU_MAX_HW_QUEUES=8 ahead of
+# the profiler instead).
 _early = _early_args(sys.argv[1:])
 _exchange = int(os.environ.get("WORLD_SIZE", "1")) > 1 or (_early.gpus or 1) > 1 or _early.force_dist
-HW_QUEUES_FROM = "environment" if "GPU_MAX_HW_QUEUES" in os.environ else "default"
-if _exchange and HW_QUEUES_FROM == "default" and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
-    HW_QUEUES_FROM = "bench.py"
+
+
+def _queue_policy(environ, exchange):
+    """(value to export or None, who set what is in effect)."""
+    had = environ.get("GPU_MAX_HW_QUEUES")
+    if not exchange or "rocprof" in environ.get("LD_PRELOAD", ""):
+        return None, ("environment" if had is not None else "HIP default")
+    if had is not None and had.isdigit() and int(had) >= 8:
+        return None, "environment"
+    return "8", "bench.py (the environment had %s)" % (had if had is not None else "no value")
+
+
+_set, HW_QUEUES_FROM = _queue_policy(os.environ, _exchange)
+if _set:
+    os.environ["GPU_MAX_HW_QUEUES"] = _set
 
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
