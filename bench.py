@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="unet", choices=["unet", "a_unet", "rdam_unet"],
+                    help="unet: the headline workload (BASELINE configs[1], 1 input channel); a_unet / rdam_unet: the "
+                         "attention-gated variants of configs[3] (3 input channels), same step, same JSON objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -246,6 +249,8 @@ def main():
     from medical_image_segmentation_amd import _lib, functional as F_
     _lib.load()
     from medical_image_segmentation_amd.model.unet import UNet
+    from medical_image_segmentation_amd.model.a_unet import A_UNet
+    from medical_image_segmentation_amd.model.rdam_unet import RDAM_UNet
     from medical_image_segmentation_amd.utils.loss_fn import diceloss
     from medical_image_segmentation_amd.utils.metrics import Metrics
     from medical_image_segmentation_amd.parallel import GradSync
@@ -255,7 +260,8 @@ def main():
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     names = ["a", "b", "c"]
     torch.manual_seed(1234)
-    model = UNet(1, 4, 0, base_channels=32, compute_dtype=cdt).to(dev).train()
+    net, cin = {"unet": (UNet, 1), "a_unet": (A_UNet, 3), "rdam_unet": (RDAM_UNet, 3)}[args.model]
+    model = net(cin, 4, 0, base_channels=32, compute_dtype=cdt).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=8e-4, betas=(0.95, 0.999), weight_decay=1e-4)
     sync = None
     if dist_on:
@@ -265,7 +271,7 @@ def main():
     loss_fn, metric = diceloss(names, global_batch=glob), Metrics(names, global_batch=glob)
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
     B, S = args.batch, args.size
-    images = torch.randn(B, 1, S, S, generator=g).to(dev)
+    images = torch.randn(B, cin, S, S, generator=g).to(dev)
     masks = torch.randint(0, 4, (B, S, S), generator=g).to(dev)
     params = [p for p in model.parameters()]
     pending = []
@@ -365,7 +371,8 @@ def main():
         if rank == 0:
             roof = F_.profile_summary(PEAK_HBM_GBS, PEAK_BF16_TFLOPS, steps=3)
             F_.PROFILE = None
-            pmc_traffic(roof["dominant"], B, S, args.dtype)
+            if args.model == "unet":
+                pmc_traffic(roof["dominant"], B, S, args.dtype)
 
     if rank == 0:
         out = {
@@ -376,7 +383,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic" + (" (copied from pinned host memory every step)" if args.h2d else ""),
-            "config": {"workload": f"UNet(in=1,classes=4,base=32) train step, batch {B}/GPU, {S}x{S}, "
+            "config": {"workload": f"{net.__name__}(in={cin},classes=4,base=32) train step, batch {B}/GPU, {S}x{S}, "
                                    f"Dice loss + confusion counts + clip + AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "dice_sums": "global batch (all-reduced)" if glob else "per rank",
@@ -397,7 +404,7 @@ def main():
             out["roofline"] = roof["dominant"]
             out["kernels"] = roof["kernels"]
             out["conv_layers"] = roof["conv_layers"]      # every conv shape against its own roof (HBM or matrix cores)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.model == "unet":
             out["cpu_baseline"] = cpu_baseline(args.cpu_threads)
         if stdout_fd is not None:
             sys.stdout.flush()

@@ -137,7 +137,11 @@ def orc_double_conv_state(cin, mid, cout, seed):
 def gold_unet(R, out):
     cases = {"unet_a": dict(B=2, cin=1, ncls=4, hw=32, seed=21),
              "unet_b": dict(B=2, cin=3, ncls=4, hw=64, seed=22),
-             "unet_c": dict(B=1, cin=1, ncls=9, hw=32, seed=23)}
+             "unet_c": dict(B=1, cin=1, ncls=9, hw=32, seed=23),
+             # seeds whose gradients do not hinge on a ReLU within round-off of zero (tools/find_stable_unet_seed.py:
+             # the oracle in float32 and in float64 agree to 5e-6 on every tensor; with seed 22 they differ by 3e-2)
+             "unet_d": dict(B=2, cin=3, ncls=4, hw=64, seed=37),
+             "unet_e": dict(B=2, cin=3, ncls=4, hw=64, seed=42)}
     for name, c in cases.items():
         m = R.UNet(c["cin"], c["ncls"], 0, base_channels=8)
         st = orc.make_state(c["cin"], c["ncls"], base=8, seed=c["seed"])

@@ -169,3 +169,53 @@ def test_rdam_unet_bf16_and_dropout(golden, report):
     m2 = RDAM_UNet(c["cin"], c["ncls"], 0.5, base_channels=c["base"], compute_dtype=torch.float32).to(DEV).train()
     y = m2(x)
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("which", ["a_unet", "rdam_unet"])
+def test_attention_variants_full_size_step_properties(which):
+    """BASELINE configs[3] at its real image size (512 x 512, 3 channels, base 32, batch 8) — beyond what the CPU
+    oracle finishes in seconds, so checked through size-independent properties of one training step: two bfloat16
+    runs from the same state are bit-identical (no floating-point atomics on the path, the gradients of the
+    four-consumer AMSFN inputs included), the confusion counts reproduce the label histogram, bfloat16 and float32
+    modes agree on the loss within the storage format's bound, and AdamW steps lower the loss."""
+    from medical_image_segmentation_amd.model.a_unet import A_UNet
+    from medical_image_segmentation_amd.model.rdam_unet import RDAM_UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    from medical_image_segmentation_amd.utils.metrics import Metrics
+    from medical_image_segmentation_amd.utils.optim import clip_and_step
+    net = A_UNet if which == "a_unet" else RDAM_UNet
+    B, S = 8, 512
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(B, 3, S, S, generator=g).to(DEV)
+    y = torch.randint(0, 4, (B, S, S), generator=g).to(DEV)
+    torch.manual_seed(17)
+    state = {k: v.clone() for k, v in net(3, 4, 0, base_channels=32).state_dict().items()}
+    loss_fn, metric = diceloss(["a", "b", "c"]), Metrics(["a", "b", "c"])
+
+    def run(dtype, steps=1):
+        m = net(3, 4, 0, base_channels=32, compute_dtype=dtype)
+        m.load_state_dict(state)
+        m = m.to(DEV).train()
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
+        out = []
+        for _ in range(steps):
+            opt.zero_grad()
+            logits = m(x)
+            ld = loss_fn(logits, y)
+            cm, status = metric.confusion_counts(logits, y)
+            ld["total_loss"].backward()
+            out.append((logits.detach().float().clone(), float(ld["total_loss"].detach()), cm.clone(),
+                        [p.grad.clone() for p in m.parameters() if p.grad is not None]))
+            clip_and_step(opt, [p for p in m.parameters() if p.grad is not None], 1.0)
+        assert int(status) == 0
+        return out
+
+    a, b = run(torch.bfloat16)[0], run(torch.bfloat16)[0]
+    assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[2], b[2])
+    assert all(torch.equal(p, q) for p, q in zip(a[3], b[3]))
+    assert all(torch.isfinite(p).all() for p in a[3])
+    assert int(a[2].sum()) == B * S * S
+    assert torch.equal(a[2].sum(dim=2).sum(dim=0).cpu(), torch.bincount(y.reshape(-1).cpu(), minlength=4))
+    f = run(torch.float32, steps=3)
+    assert abs(a[1] - f[0][1]) < 2e-2
+    assert f[2][1] < f[0][1]

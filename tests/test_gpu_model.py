@@ -31,7 +31,9 @@ def build(c, dtype):
 
 UNET_CASES = [("unet_a", dict(B=2, cin=1, ncls=4, hw=32, seed=21)),
               ("unet_b", dict(B=2, cin=3, ncls=4, hw=64, seed=22)),
-              ("unet_c", dict(B=1, cin=1, ncls=9, hw=32, seed=23))]
+              ("unet_c", dict(B=1, cin=1, ncls=9, hw=32, seed=23)),
+              ("unet_d", dict(B=2, cin=3, ncls=4, hw=64, seed=37)),
+              ("unet_e", dict(B=2, cin=3, ncls=4, hw=64, seed=42))]
 
 
 def _grad_deviation(m, g, name):
@@ -54,24 +56,51 @@ def _grad_deviation(m, g, name):
 LOGITS_FP32_TOL = 1e-5      # (measured: 2-3e-6 on both conv paths)
 
 
+def _oracle_grads(c, dtype):
+    """Gradients of the CPU oracle in `dtype` on the case's weights and batch (conv biases under BatchNorm left out)."""
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100))
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+    st = orc.make_state(c["cin"], c["ncls"], base=8, seed=c["seed"], dtype=dtype)
+    keys = [k for k in orc.param_keys(st) if not (k.endswith(".0.bias") and k != "out_conv.bias")]
+    for k in orc.param_keys(st):
+        st[k].requires_grad_(True)
+    lo = orc.unet_forward(x.to(dtype), st, training=True)
+    orc.dice_loss(lo, t, [f"c{i}" for i in range(1, c["ncls"])])["total_loss"].backward()
+    return {k: st[k].grad.double() for k in keys}
+
+
+def _deviation(a, b):
+    """(worst per-tensor norm deviation, worst element deviation relative to the tensor's scale) of gradient dicts."""
+    dn = max(abs(float(a[k].norm()) - float(b[k].norm())) / (float(b[k].norm()) + 1e-12) for k in b)
+    de = max(float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-30)) for k in b)
+    return dn, de
+
+
 @pytest.mark.parametrize("name,c", UNET_CASES)
 def test_unet_fp32_golden(golden, report, name, c):
-    """float32 forward + backward of the whole network against the reference's own outputs.
+    """float32 forward + backward of the whole network against the reference's own outputs, on the default conv
+    path (matrix-core kernels where taken) and on the vector-ALU path.
 
-    Forward: logits 1e-5 (measured 2-3e-6), losses 1e-5.  Gradients: 5e-3.  The Dice gradient is concentrated on few
-    pixels, and a 1e-6 forward difference — the size of the difference between our two conv kernel
-    families, or between either and the reference's CPU arithmetic — can flip the ReLU mask of ONE
-    pixel that carries a large gradient; in a 2-channel BatchNorm of this tiny network that moves
-    the channel sums, and everything upstream, by a few per cent (measured on unet_b: one such
-    pixel in decoder4.cbr1).  So the 5e-3 bound must hold on at least one of the two kernel
-    families (matrix-core where taken, or vector-ALU only), and 10 % on both."""
+    Forward: logits 1e-5 (measured 2-8e-6), losses 1e-5.  Gradients, on BOTH paths: every tensor within 5e-3 (norm,
+    and elements relative to the tensor's scale) of the reference's fixture and of the float64 oracle — whenever the
+    fixture is insensitive to float32 round-off, which is measured, not assumed: the Dice gradient is concentrated on
+    few pixels, and a ReLU whose pre-activation lies within round-off of zero at such a pixel moves whole tensors by
+    per cents in the 2-channel BatchNorm layers of these base-8 networks.  The oracle run in float32 and in float64 —
+    the same arithmetic at two precisions — tells the cases apart: the two agree to ~1e-5 on unet_a/c/d/e (fixtures
+    d and e were chosen that way, tools/find_stable_unet_seed.py) and differ by 3.3e-2 (norms) / 6.3e-2 (elements)
+    on unet_b.  On such a fixture this implementation must still agree to 5e-3 with ONE of the two precisions of
+    the oracle (it takes the float32 oracle's side of that ReLU), and stay within 10 % of the reference's fixture."""
     from medical_image_segmentation_amd import _lib
     from medical_image_segmentation_amd.utils.loss_fn import diceloss
     g = golden("unet")
     x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(DEV)
     t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300)).to(DEV)
     names = [f"c{i}" for i in range(1, c["ncls"])]
-    strict = []
+    o64, o32 = _oracle_grads(c, torch.float64), _oracle_grads(c, torch.float32)
+    sens = max(_deviation(o32, o64))
+    report("float32-vs-float64 oracle gradient deviation (sensitivity of the fixture)", sens)
+    fixture_is_stable = sens < 1e-3
+    assert fixture_is_stable == (name != "unet_b")
     for mode in (0, 1):
         _lib.call("mis_set_conv_path", mode)
         try:
@@ -88,10 +117,18 @@ def test_unet_fp32_golden(golden, report, name, c):
             assert e_logits < LOGITS_FP32_TOL
             np.testing.assert_allclose(got_loss, g[f"{name}.loss"], rtol=1e-5, atol=1e-6)
             dev, sdev = _grad_deviation(m, g, name)
-            report(f"conv path {mode}: fp32 gradient norm deviation (worst tensor)", float(dev.max()))
-            report(f"conv path {mode}: fp32 gradient sample deviation (worst tensor)", float(sdev.max()))
-            assert dev.max() < 0.10 and sdev.max() < 0.10, (mode, dev.max(), sdev.max())
-            strict.append(bool(dev.max() < 5e-3 and sdev.max() < 5e-3))
+            report(f"conv path {mode}: fp32 gradient norm deviation vs reference fixture (worst tensor)", float(dev.max()))
+            report(f"conv path {mode}: fp32 gradient sample deviation vs reference fixture (worst tensor)", float(sdev.max()))
+            params = dict(m.named_parameters())
+            got = {k: params[k].grad.double().cpu() for k in o64}
+            d64, d32 = max(_deviation(got, o64)), max(_deviation(got, o32))
+            report(f"conv path {mode}: fp32 gradient deviation vs float64 oracle (worst tensor, norm or element)", d64)
+            report(f"conv path {mode}: fp32 gradient deviation vs float32 oracle (worst tensor, norm or element)", d32)
+            if fixture_is_stable:
+                assert d64 < 5e-3 and dev.max() < 5e-3 and sdev.max() < 5e-3, (mode, d64, dev.max(), sdev.max())
+            else:
+                assert min(d64, d32) < 5e-3, (mode, d64, d32)
+                assert dev.max() < 0.10 and sdev.max() < 0.10, (mode, dev.max(), sdev.max())
             assert rel_err(m.center_conv.cbr1[1].running_mean, g[f"{name}.running_mean.center_conv.cbr1"]) < 1e-4
             assert rel_err(m.center_conv.cbr1[1].running_var, g[f"{name}.running_var.center_conv.cbr1"]) < 1e-4
             m.eval()
@@ -99,7 +136,6 @@ def test_unet_fp32_golden(golden, report, name, c):
                 assert rel_err(m(x), g[f"{name}.eval_logits"]) < 1e-4
         finally:
             _lib.call("mis_set_conv_path", 0)
-    assert any(strict), strict
 
 
 @pytest.mark.parametrize("name,c", UNET_CASES)

@@ -122,6 +122,25 @@ def test_slide_exact_against_oracle(sp, h, w, ws, st, batch):
     assert np.array_equal(res, ref)
 
 
+@pytest.mark.parametrize("ws,st,tiles,unique", [(1024, 512, 64, 49), (256, 128, 1024, 961)])
+def test_slide_full_size_4096_against_oracle(sp, ws, st, tiles, unique):
+    """BASELINE configs[4] at its real size: a 4096 x 4096 x 3 uint8 slide, window 1024 / stride 512 (predict.py:86-91)
+    and the class defaults 256 / 128 (utils/slide_predict.py:8): the tile list — 64 tiles of which 49 are distinct,
+    1024 / 961 — and the final uint8 map, bit for bit against the oracle's tile-by-tile float32 accumulation."""
+    ncls = 4
+    img = np.random.default_rng(4096 + ws).integers(0, 256, (4096, 4096, 3), dtype=np.uint8)
+    pred = sp.SlidingWindowPredictor(IntClassModel(ncls), DEV, ws, st)
+    res = pred.predict_array(img)
+    padded, _ = orc.slide_pad(img, ws, st)
+    pos = orc.slide_positions(padded.shape[0], padded.shape[1], ws, st)
+    assert pos == pred._split_image(padded)
+    assert len(pos) == tiles and len(set(pos)) == unique
+    maps = [int_class_of(padded[y0:y1, x0:x1], ncls) for (y0, y1, x0, x1) in pos]
+    ref = orc.slide_blend(maps, pos, padded.shape[:2], img.shape[:2], ws)
+    assert res.shape == (4096, 4096) and res.dtype == np.uint8
+    assert np.array_equal(res, ref)
+
+
 def test_slide_predict_files(sp, tmp_path):
     from PIL import Image
     img = (dg.hash_u64((40, 56, 3), 92) % np.uint64(256)).astype(np.uint8)

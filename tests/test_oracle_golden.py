@@ -43,7 +43,9 @@ def test_double_conv(golden, name, c):
 
 @pytest.mark.parametrize("name,c", [("unet_a", dict(B=2, cin=1, ncls=4, hw=32, seed=21)),
                                     ("unet_b", dict(B=2, cin=3, ncls=4, hw=64, seed=22)),
-                                    ("unet_c", dict(B=1, cin=1, ncls=9, hw=32, seed=23))])
+                                    ("unet_c", dict(B=1, cin=1, ncls=9, hw=32, seed=23)),
+                                    ("unet_d", dict(B=2, cin=3, ncls=4, hw=64, seed=37)),
+                                    ("unet_e", dict(B=2, cin=3, ncls=4, hw=64, seed=42))])
 def test_unet(golden, name, c):
     g = golden("unet")
     # float64 oracle: the reference's CPU BatchNorm accumulates in double, and the
