@@ -388,6 +388,19 @@ int mis_conv1x1_bwd(const void* x, const float* x_affine, const void* dy, int dt
 /* channels-last activations inside).                                           */
 int mis_nchw_f32_to_nhwc(const float* x, int B, int C, int H, int W, int dtype, void* y, mis_stream_t stream);
 
+/* One activation read by several consumers (the input of an AMSFN block feeds four branches,  */
+/* model/utils/modules.py:846-856; an encoder output feeds its block and the decoder's skip,    */
+/* model/a_unet.py:66-105): autograd adds the consumers' gradients pairwise, one full pass per  */
+/* addition.  out = grads[0] + ... + grads[n-1] (2 <= n <= 5) in ONE pass, summed in float32 in */
+/* slot order and rounded once.  With bn_sums (float32 [2][C]) the activation is the lazy       */
+/* output relu(bn(z)) of a training-mode layer (z_affine4 = [4][C]: scale, shift, mean, rstd)   */
+/* and the kernel also returns that layer's BatchNorm-backward sums of `out` as stored,         */
+/*   bn_sums[0][c] = sum out*[y>0],  bn_sums[1][c] = sum out*[y>0]*xhat,                         */
+/* i.e. what mis_bn_relu_bwd_reduce(z, out) would compute in a pass of its own.                  */
+size_t mis_sum_gradients_workspace_bytes(int C);
+int mis_sum_gradients(const void* const* grads, int n_grads, int dtype, int64_t n_pix, int C, const void* z,
+                      const float* z_affine4, void* out, float* bn_sums, void* workspace, mis_stream_t stream);
+
 /* ------------------------------------------------------------------------- */
 /* AMSFN multi-scale fusion block of A_UNet (model/utils/modules.py:791-871,     */
 /* model/a_unet.py:27-30,48-51): everything that is not a convolution.            */

@@ -21,6 +21,12 @@ constexpr int TPB = 256;
 // maximum, NaN maximal — the scan order of torch's kernel) supplied the value; the backward is
 // then a gather: input pixel p receives dy[q] from each of the <= 9 windows q whose recorded
 // position is p.
+// A thread owns MP3_R consecutive output rows of one column and channel vector.  The maximum is taken in two
+// steps that keep the scan order: first along each input row (3 taps, first maximum), then down the three
+// rows of a window (first maximum again) — a row's result serves up to three output rows, so an output costs
+// (MP3_R+2)*3/MP3_R loads and lazy-input conversions instead of 9.
+constexpr int MP3_R = 4;
+
 template <typename T, int V>
 __global__ __launch_bounds__(TPB) void maxpool3_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                            uint8_t* __restrict__ arg, int B, int H, int W, int C,
@@ -32,42 +38,90 @@ __global__ __launch_bounds__(TPB) void maxpool3_fwd_kernel(const T* __restrict__
     __syncthreads();
     aff = aff_lds;
   }
-  const int CV = C / V;
-  const int64_t total = (int64_t)B * H * W * CV;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
-    const int cv = (int)(i % CV);
-    int64_t p = i / CV;
-    const int xo = (int)(p % W);
-    p /= W;
-    const int yo = (int)(p % H);
-    const int b = (int)(p / H);
-    float m[V];
-    int am[V];
-    bool have = false;
+  // 32-bit item arithmetic (the host checks the item count): 64-bit division is emulated
+  const unsigned CV = (unsigned)(C / V), HS = (unsigned)((H + MP3_R - 1) / MP3_R);
+  const unsigned total = (unsigned)B * HS * (unsigned)W * CV;
+  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
+    const unsigned cv = i % CV;
+    unsigned p = i / CV;
+    const int xo = (int)(p % (unsigned)W);
+    p /= (unsigned)W;
+    const int y0 = (int)(p % HS) * MP3_R;
+    const int b = (int)(p / HS);
+    float hm[3][V];          // per input row: maximum of its 3 taps ...
+    int ha[3][V];            // ... and which tap (0..2) supplied it
+    bool hv[3];              // row inside the image
 #pragma unroll
-    for (int k = 0; k < V; k++) { m[k] = 0.f; am[k] = 0; }
+    for (int q = 0; q < 3; q++)
 #pragma unroll
-    for (int dy = -1; dy <= 1; dy++) {
+      for (int k = 0; k < V; k++) { hm[q][k] = -INFINITY; ha[q][k] = 0; }
 #pragma unroll
-      for (int dx = -1; dx <= 1; dx++) {
-        const int yy = yo + dy, xx = xo + dx;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;       // padding never wins
-        float v[V];
-        vload<T, V>(x + (((int64_t)b * H + yy) * W + xx) * C + cv * V, v);
-        affine_relu_rounded<T, V>(v, aff, C, cv * V);
-        const int pos = (dy + 1) * 3 + (dx + 1);
+    for (int r = 0; r < MP3_R + 2; r++) {
+      const int s = r % 3, yy = y0 - 1 + r;
+      hv[s] = yy >= 0 && yy < H;
+      if (hv[s]) {
+        // start below everything at the first tap inside the image: a later tap wins only if greater, or NaN
+        // over a number (`!(v <= m)` holds for both; `m == m` keeps the first NaN)
+#pragma unroll
+        for (int k = 0; k < V; k++) { hm[s][k] = -INFINITY; ha[s][k] = xo > 0 ? 0 : 1; }
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+          const int xx = xo + dx;
+          if (xx < 0 || xx >= W) continue;                             // padding never wins
+          float v[V];
+          vload<T, V>(x + (((int64_t)b * H + yy) * W + xx) * C + cv * V, v);
+          affine_relu_rounded<T, V>(v, aff, C, cv * V);
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            const bool take = !(v[k] <= hm[s][k]) && (hm[s][k] == hm[s][k]);
+            hm[s][k] = take ? v[k] : hm[s][k];
+            ha[s][k] = take ? dx + 1 : ha[s][k];
+          }
+        }
+      }
+      if (r < 2) continue;
+      const int yo = y0 + r - 2;                                       // window rows: slots (r-2)%3, (r-1)%3, r%3
+      if (yo >= H) continue;
+      float m[V];
+      int am[V];
+      const bool top = hv[(r - 2) % 3];                                // else the window starts at its centre row
+#pragma unroll
+      for (int k = 0; k < V; k++) {
+        m[k] = -INFINITY;
+        am[k] = top ? ha[(r - 2) % 3][k] : 3 + ha[(r - 1) % 3][k];
+      }
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const int q = (r - 2 + d) % 3;
+        if (!hv[q]) continue;
 #pragma unroll
         for (int k = 0; k < V; k++) {
-          const bool take = !have || (v[k] > m[k]) || (v[k] != v[k] && m[k] == m[k]);
-          m[k] = take ? v[k] : m[k];
-          am[k] = take ? pos : am[k];
+          const bool take = !(hm[q][k] <= m[k]) && (m[k] == m[k]);
+          m[k] = take ? hm[q][k] : m[k];
+          am[k] = take ? d * 3 + ha[q][k] : am[k];
         }
-        have = true;
+      }
+      const int64_t o = ((((int64_t)b * H + yo) * W + xo) * CV + cv) * V;
+      vstore<T, V>(y + o, m);
+      // the V window positions of this vector as one store (V single-byte stores cost V store instructions)
+      if constexpr (V == 8) {
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          lo |= (unsigned)am[k] << (8 * k);
+          hi |= (unsigned)am[4 + k] << (8 * k);
+        }
+        *reinterpret_cast<uint2*>(arg + o) = uint2{lo, hi};
+      } else if constexpr (V == 4) {
+        unsigned lo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) lo |= (unsigned)am[k] << (8 * k);
+        *reinterpret_cast<unsigned*>(arg + o) = lo;
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; k++) arg[o + k] = (uint8_t)am[k];
       }
     }
-    vstore<T, V>(y + i * V, m);
-#pragma unroll
-    for (int k = 0; k < V; k++) arg[i * V + k] = (uint8_t)am[k];
   }
 }
 
@@ -389,14 +443,16 @@ int mis_maxpool3x3s1_fwd(const void* x, const float* x_affine, int dtype, int B,
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1 && C <= 4096, "maxpool3x3s1_fwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = x_affine ? 2 * (size_t)C * sizeof(float) : 0;
-  const int64_t n = (int64_t)B * H * W * C;
+  // items: one per (image, strip of MP3_R rows, column, channel vector)
+  const int64_t n = (int64_t)B * ((H + MP3_R - 1) / MP3_R) * W * C;
+  MIS_REQUIRE(n < ((int64_t)1 << 31), "maxpool3x3s1_fwd: tensor too large for 32-bit item arithmetic");
   if (dtype == MIS_BF16) {
-    if (pick_vec<bf16>(C, x, y) == 8)
+    if (pick_vec<bf16>(C, x, y, argmax) == 8)
       maxpool3_fwd_kernel<bf16, 8><<<ew_grid(n / 8, TPB), TPB, lds, st>>>((const bf16*)x, (bf16*)y, argmax, B, H, W, C, x_affine);
     else
       maxpool3_fwd_kernel<bf16, 1><<<ew_grid(n, TPB), TPB, lds, st>>>((const bf16*)x, (bf16*)y, argmax, B, H, W, C, x_affine);
   } else if (dtype == MIS_F32) {
-    if (pick_vec<float>(C, x, y) == 4)
+    if (pick_vec<float>(C, x, y, argmax) == 4)
       maxpool3_fwd_kernel<float, 4><<<ew_grid(n / 4, TPB), TPB, lds, st>>>((const float*)x, (float*)y, argmax, B, H, W, C, x_affine);
     else
       maxpool3_fwd_kernel<float, 1><<<ew_grid(n, TPB), TPB, lds, st>>>((const float*)x, (float*)y, argmax, B, H, W, C, x_affine);
@@ -509,6 +565,110 @@ int fuse_bwd_t(const Branches& br, const Grads& gr, const void* dout, int B, int
   return MIS_OK;
 }
 
+
+// ---- several consumers of one activation: their gradients summed in ONE pass ----------------------
+// out = g0 + g1 (+ g2 + g3 + g4), added in float32 in slot order and rounded once.  When the activation is
+// the lazy output relu(bn(z)) of a training-mode layer (z and its [4][C] affine given), the kernel also
+// accumulates that layer's BatchNorm-backward sums of the summed gradient as it is stored —
+// sum out*[y>0] and sum out*[y>0]*xhat — as one partial row per workgroup (fixed channel vector per thread,
+// fixed-order block reduction), so the layer's own reduction pass over (z, gradient) disappears.
+constexpr int SUM_MAX = 5;
+struct SumPtrs {
+  const void* g[SUM_MAX];
+};
+template <typename T, int V, int N>
+__global__ __launch_bounds__(TPB) void sum_gradients_kernel(SumPtrs src, T* __restrict__ out, int64_t n_vec, int C,
+                                                            const T* __restrict__ z, const float* __restrict__ aff4,
+                                                            float* __restrict__ bn_partials) {
+  __shared__ float red[TPB * 2 * V];
+  const int CV = C / V;
+  const int64_t i0 = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const int c0 = (int)(i0 % CV) * V;             // fixed for this thread when sums are wanted (the grid is sized for that)
+  float sc[V], sh[V], mu[V], rs[V], bs[2][V];
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    sc[k] = bn_partials ? aff4[c0 + k] : 0.f;
+    sh[k] = bn_partials ? aff4[C + c0 + k] : 0.f;
+    mu[k] = bn_partials ? aff4[2 * C + c0 + k] : 0.f;
+    rs[k] = bn_partials ? aff4[3 * C + c0 + k] : 0.f;
+    bs[0][k] = bs[1][k] = 0.f;
+  }
+  for (int64_t i = i0; i < n_vec; i += (int64_t)gridDim.x * TPB) {
+    float acc[V], t[V];
+    vload<T, V>((const T*)src.g[0] + i * V, acc);
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+      vload<T, V>((const T*)src.g[j] + i * V, t);
+#pragma unroll
+      for (int k = 0; k < V; k++) acc[k] += t[k];
+    }
+    vstore<T, V>(out + i * V, acc);
+    if (bn_partials) {
+      float zv[V];
+      vload<T, V>(z + i * V, zv);
+#pragma unroll
+      for (int k = 0; k < V; k++) {
+        const bool on = zv[k] * sc[k] + sh[k] > 0.f;
+        const float d = on ? to_f32(from_f32<T>(acc[k])) : 0.f;      // the value the next pass would read
+        bs[0][k] += d;
+        bs[1][k] = on ? __builtin_fmaf(d, (zv[k] - mu[k]) * rs[k], bs[1][k]) : bs[1][k];
+      }
+    }
+  }
+  if (bn_partials) {
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int k = 0; k < V; k++) red[(threadIdx.x * 2 + q) * V + k] = bs[q][k];
+    __syncthreads();
+    const int base = (int)(((int64_t)blockIdx.x * TPB) % CV);
+    for (int j = threadIdx.x; j < 2 * C; j += TPB) {
+      const int q = j / C, c = j % C, cv = c / V, k = c % V;
+      float a = 0.f;
+      for (int t = (cv - base + CV) % CV; t < TPB; t += CV) a += red[(t * 2 + q) * V + k];
+      bn_partials[(int64_t)blockIdx.x * 2 * C + j] = a;
+    }
+  }
+}
+
+constexpr int SUM_MAX_ROWS = 1536;
+
+template <typename T, int V, int N>
+void launch_sum_n(const SumPtrs& src, void* out, int64_t n, int C, const void* z, const float* aff4, float* bn_sums,
+                  void* ws, hipStream_t st) {
+  int grid = ew_grid(n / V, TPB);
+  float* partials = nullptr;
+  if (bn_sums) {
+    grid = grid_for_fixed_channels(grid, C / V, SUM_MAX_ROWS);
+    partials = (float*)ws;
+  }
+  sum_gradients_kernel<T, V, N><<<grid, TPB, 0, st>>>(src, (T*)out, n / V, C, (const T*)z, aff4, partials);
+  if (bn_sums) launch_reduce_partials(partials, grid, 2 * C, bn_sums, st);
+}
+
+template <typename T>
+int sum_gradients_t(const SumPtrs& src, int n_src, void* out, int64_t n_pix, int C, const void* z, const float* aff4,
+                    float* bn_sums, void* ws, hipStream_t st) {
+  constexpr int NV = VecOf<T>::N;
+  bool vec = pick_vec<T>(C, out, z) == NV && C / NV <= TPB;
+  for (int j = 0; j < n_src; j++) vec = vec && ((uintptr_t)src.g[j] % 16) == 0;
+  const int64_t n = n_pix * C;
+#define SUM_DISPATCH(V_)                                                                            \
+  switch (n_src) {                                                                                  \
+    case 2: launch_sum_n<T, V_, 2>(src, out, n, C, z, aff4, bn_sums, ws, st); break;                \
+    case 3: launch_sum_n<T, V_, 3>(src, out, n, C, z, aff4, bn_sums, ws, st); break;                \
+    case 4: launch_sum_n<T, V_, 4>(src, out, n, C, z, aff4, bn_sums, ws, st); break;                \
+    default: launch_sum_n<T, V_, 5>(src, out, n, C, z, aff4, bn_sums, ws, st); break;               \
+  }
+  if (vec) {
+    SUM_DISPATCH(NV)
+  } else {
+    SUM_DISPATCH(1)
+  }
+#undef SUM_DISPATCH
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -558,6 +718,30 @@ int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const
                             (hipStream_t)stream);
   return fuse_bwd_t<float>(br, gr, dout, B, HW, C, W1, W2, s, h, w, dW1, db1, dW2, db2, workspace,
                            (hipStream_t)stream);
+}
+
+size_t mis_sum_gradients_workspace_bytes(int C) {
+  return C >= 1 ? align256((size_t)SUM_MAX_ROWS * 2 * C * sizeof(float)) + 256 : 0;
+}
+
+int mis_sum_gradients(const void* const* grads, int n_grads, int dtype, int64_t n_pix, int C, const void* z,
+                      const float* z_affine4, void* out, float* bn_sums, void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(grads && out, "sum_gradients: null pointer");
+  MIS_REQUIRE(n_grads >= 2 && n_grads <= SUM_MAX, "sum_gradients: 2..%d gradients (got %d)", SUM_MAX, n_grads);
+  MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 4096, "sum_gradients: bad shape");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "sum_gradients: bad dtype %d", dtype);
+  MIS_REQUIRE(!bn_sums || (z && z_affine4 && workspace), "sum_gradients: the BatchNorm sums need z, its [4][C] affine and a workspace");
+  MIS_REQUIRE(!bn_sums || (C % (dtype == MIS_BF16 ? 8 : 4) == 0 && C / (dtype == MIS_BF16 ? 8 : 4) <= TPB),
+              "sum_gradients: the BatchNorm sums need whole 16-byte channel vectors (C=%d)", C);
+  SumPtrs src;
+  for (int j = 0; j < SUM_MAX; j++) {
+    src.g[j] = j < n_grads ? grads[j] : nullptr;
+    MIS_REQUIRE(j >= n_grads || grads[j], "sum_gradients: null gradient %d", j);
+  }
+  if (dtype == MIS_BF16) sum_gradients_t<bf16>(src, n_grads, out, n_pix, C, z, z_affine4, bn_sums, workspace, (hipStream_t)stream);
+  else sum_gradients_t<float>(src, n_grads, out, n_pix, C, z, z_affine4, bn_sums, workspace, (hipStream_t)stream);
+  MIS_CHECK_LAUNCH("sum_gradients_kernel");
+  return MIS_OK;
 }
 
 int mis_dwconv_compose_fwd(const float* P, const float* D, const float* bd, const float* bp, int Cout, int Cin,

@@ -35,27 +35,29 @@ __global__ void pack_w3x3_kernel(const float* __restrict__ w, int Cout, int Cin,
 // ---------------------------------------------------------------------------------
 // direct 3x3 forward: one thread = one pixel x CO_T output channels
 // ---------------------------------------------------------------------------------
-template <typename T, int V>
+// COT: output channels per thread (8, or fewer for narrow layers: with 8 a 1-channel output spends 7/8 of its
+// multiply-adds and LDS weight reads on padding)
+template <typename T, int V, int COT = CO_T>
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
     const T* __restrict__ x, const T* __restrict__ wp /*[9][Cout][Cin]*/, const float* __restrict__ bias,
     T* __restrict__ z, float* __restrict__ partials /*[gridDim.x][2][Cout] or null*/, int B, int H, int W, int Cin,
     int Cout, const float* __restrict__ in_aff) {
-  __shared__ float wl[9][CI_CHUNK][CO_T];
-  __shared__ float red[2 * CO_T * (CD_THREADS / 64)];
+  __shared__ float wl[9][CI_CHUNK][COT];
+  __shared__ float red[2 * COT * (CD_THREADS / 64)];
   const int tid = threadIdx.x;
-  const int co0 = blockIdx.y * CO_T;
+  const int co0 = blockIdx.y * COT;
   const int64_t n_pix = (int64_t)B * H * W;
   const bool one_chunk = Cin <= CI_CHUNK;           // weights staged once for the whole pixel walk
-  float st[2 * CO_T];
+  float st[2 * COT];
 #pragma unroll
-  for (int j = 0; j < 2 * CO_T; j++) st[j] = 0.f;
-  float bv[CO_T];
+  for (int j = 0; j < 2 * COT; j++) st[j] = 0.f;
+  float bv[COT];
 #pragma unroll
-  for (int j = 0; j < CO_T; j++) bv[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
+  for (int j = 0; j < COT; j++) bv[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
 
   auto stage_w = [&](int c0, int cn) {
-    for (int i = tid; i < 9 * CI_CHUNK * CO_T; i += CD_THREADS) {
-      const int j = i % CO_T, ci = (i / CO_T) % CI_CHUNK, tap = i / (CO_T * CI_CHUNK);
+    for (int i = tid; i < 9 * CI_CHUNK * COT; i += CD_THREADS) {
+      const int j = i % COT, ci = (i / COT) % CI_CHUNK, tap = i / (COT * CI_CHUNK);
       float v = 0.f;
       if (ci < cn && co0 + j < Cout) v = to_f32(wp[((int64_t)tap * Cout + co0 + j) * Cin + c0 + ci]);
       wl[tap][ci][j] = v;
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
       px = (int)(p32 - row * (unsigned)W);
       py = (int)(row % (unsigned)H);
     }
-    float acc[CO_T];
+    float acc[COT];
 #pragma unroll
-    for (int j = 0; j < CO_T; j++) acc[j] = 0.f;
+    for (int j = 0; j < COT; j++) acc[j] = 0.f;
     for (int c0 = 0; c0 < Cin; c0 += CI_CHUNK) {
       const int cn = (Cin - c0 < CI_CHUNK) ? (Cin - c0) : CI_CHUNK;
       if (!one_chunk) {
@@ -99,43 +101,48 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
 #pragma unroll
             for (int k = 0; k < V; k++)
 #pragma unroll
-              for (int j = 0; j < CO_T; j++) acc[j] += xv[k] * wl[tap][ci + k][j];
+              for (int j = 0; j < COT; j++) acc[j] += xv[k] * wl[tap][ci + k][j];
           }
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < CO_T; j++) {
+    for (int j = 0; j < COT; j++) {
       acc[j] += bv[j];
       if (valid) {
         st[j] += acc[j];
-        st[CO_T + j] += acc[j] * acc[j];
+        st[COT + j] += acc[j] * acc[j];
       }
     }
     if (valid) {
       T* zp = z + pix * Cout + co0;
-      if (co0 + CO_T <= Cout && (Cout % CO_T) == 0 && sizeof(T) * CO_T >= 16) {
-        if constexpr (sizeof(T) == 2) {
-          vstore<T, CO_T>(zp, acc);
-        } else {
-          float lo[4] = {acc[0], acc[1], acc[2], acc[3]}, hi[4] = {acc[4], acc[5], acc[6], acc[7]};
-          vstore<T, 4>(zp, lo);
-          vstore<T, 4>(zp + 4, hi);
+      bool stored = false;
+      if constexpr (sizeof(T) * COT >= 16) {
+        if (co0 + COT <= Cout && (Cout % COT) == 0) {
+          stored = true;
+          if constexpr (sizeof(T) * COT == 16) {
+            vstore<T, COT>(zp, acc);
+          } else {
+            float lo[4] = {acc[0], acc[1], acc[2], acc[3]}, hi[4] = {acc[4], acc[5], acc[6], acc[7]};
+            vstore<T, 4>(zp, lo);
+            vstore<T, 4>(zp + 4, hi);
+          }
         }
-      } else {
+      }
+      if (!stored) {
 #pragma unroll
-        for (int j = 0; j < CO_T; j++)
+        for (int j = 0; j < COT; j++)
           if (co0 + j < Cout) zp[j] = from_f32<T>(acc[j]);
       }
     }
   }
   if (partials) {
-    block_sum<2 * CO_T>(st, red);
-    if (tid < 2 * CO_T) {
+    block_sum<2 * COT>(st, red);
+    if (tid < 2 * COT) {
       float v = 0.f;
 #pragma unroll
-      for (int i = 0; i < 2 * CO_T; i++) v = (tid == i) ? st[i] : v;
-      const int which = tid / CO_T, j = tid % CO_T;
+      for (int i = 0; i < 2 * COT; i++) v = (tid == i) ? st[i] : v;
+      const int which = tid / COT, j = tid % COT;
       if (co0 + j < Cout) partials[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + j] = v;
     }
   }
@@ -720,20 +727,27 @@ int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const
       if (Cin == 1) FIRST_LAUNCH(bf16, 1); else FIRST_LAUNCH(bf16, 3);
     }
 #undef FIRST_LAUNCH
-  } else if (dtype == MIS_F32) {
-    if (Cin % 4 == 0 && ((uintptr_t)x % 16) == 0)
-      conv3x3_direct_kernel<float, 4><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)wp, bias, (float*)z,
-                                                                    partials, B, H, W, Cin, Cout, in_aff);
-    else
-      conv3x3_direct_kernel<float, 1><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)wp, bias, (float*)z,
-                                                                    partials, B, H, W, Cin, Cout, in_aff);
   } else {
-    if (Cin % 8 == 0 && ((uintptr_t)x % 16) == 0)
-      conv3x3_direct_kernel<bf16, 8><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)wp, bias, (bf16*)z,
-                                                                   partials, B, H, W, Cin, Cout, in_aff);
-    else
-      conv3x3_direct_kernel<bf16, 1><<<grid, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)wp, bias, (bf16*)z,
-                                                                   partials, B, H, W, Cin, Cout, in_aff);
+    // narrow outputs take fewer channels per thread
+    const int cot = Cout <= 1 ? 1 : Cout <= 2 ? 2 : Cout <= 4 ? 4 : CO_T;
+    grid.y = cdiv(Cout, cot);
+#define DIRECT_LAUNCH(TT, VV, COT_)                                                                          \
+  conv3x3_direct_kernel<TT, VV, COT_><<<grid, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)wp, bias, (TT*)z, \
+                                                                  partials, B, H, W, Cin, Cout, in_aff)
+#define DIRECT_COT(TT, VV)                                                                                   \
+  switch (cot) {                                                                                             \
+    case 1: DIRECT_LAUNCH(TT, VV, 1); break;                                                                 \
+    case 2: DIRECT_LAUNCH(TT, VV, 2); break;                                                                 \
+    case 4: DIRECT_LAUNCH(TT, VV, 4); break;                                                                 \
+    default: DIRECT_LAUNCH(TT, VV, CO_T); break;                                                             \
+  }
+    if (dtype == MIS_F32) {
+      if (Cin % 4 == 0 && ((uintptr_t)x % 16) == 0) DIRECT_COT(float, 4) else DIRECT_COT(float, 1)
+    } else {
+      if (Cin % 8 == 0 && ((uintptr_t)x % 16) == 0) DIRECT_COT(bf16, 8) else DIRECT_COT(bf16, 1)
+    }
+#undef DIRECT_COT
+#undef DIRECT_LAUNCH
   }
   MIS_CHECK_LAUNCH("conv3x3_direct_kernel");
   if (stats && (void*)stats != workspace) {      // stats == workspace: the caller reduces the partial rows itself

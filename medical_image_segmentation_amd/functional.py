@@ -623,6 +623,9 @@ def _wants_bn_sums(x_ss, numel):
             and numel >= BN_SUMS_MIN_NUMEL)
 
 
+DGRAD_BN_SUMS_MIN_PIXELS = 0     # per image: below this the data gradient leaves the sums to the layer's own pass
+
+
 def _dgrad_with_bn_sums(dz, wd, x, x_ss):
     """Data gradient of a conv whose input x is a lazy activation with batch statistics riding
     along (x_ss = [scale, shift, mean, rstd]): the kernel also accumulates the BatchNorm-backward
@@ -632,6 +635,8 @@ def _dgrad_with_bn_sums(dz, wd, x, x_ss):
         return None
     B, Cout, H, W = x.shape                 # the data gradient produces x's channels
     Cin = dz.shape[1]
+    if H * W < DGRAD_BN_SUMS_MIN_PIXELS:
+        return None
     if not query("mis_conv3x3_dgrad_bn_sums_supported", _dt(x), B, H, W, Cin, Cout):
         return None
     dx = torch.empty_like(x)
@@ -1118,6 +1123,61 @@ class MaxPool3x3Fn(torch.autograd.Function):
 
 def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+class FanOutFn(torch.autograd.Function):
+    """One activation (lazy or plain) read by n consumers: returns n aliases of it and, in the backward pass, sums the
+    consumers' gradients in ONE kernel instead of autograd's pairwise additions (a full pass each) — the four branches
+    of an AMSFN block read its input (model/utils/modules.py:846-856), an encoder output of A_UNet feeds its block and
+    the decoder's skip (model/a_unet.py:66-105).  With `bn_sums` and a training-mode lazy input the same kernel returns
+    the BatchNorm-backward sums of the producing layer (the summed gradient is in registers, z is read alongside), and
+    the gradient tensor carries them to that layer's backward, which then skips its reduction pass; pass
+    bn_sums=False when the activation has consumers outside this fan-out (their gradients are added later)."""
+
+    @staticmethod
+    def forward(ctx, x, x_ss, n, bn_sums):
+        ctx.set_materialize_grads(False)
+        ctx.bn_sums = bool(bn_sums)
+        ctx.save_for_backward(x, x_ss)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, x_ss = ctx.saved_tensors
+        gs = [to_act(g, x.dtype) for g in grads if g is not None]
+        if not gs:
+            return None, None, None, None
+        if len(gs) == 1:
+            return gs[0], None, None, None
+        if len(gs) > 5 or any(g.shape != x.shape for g in gs):
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None, None, None
+        B, Cc, H, W = x.shape
+        out = torch.empty_like(x)
+        # (any size: the extra read of z costs one pass of this kernel, the reduction pass it replaces two and a launch)
+        want = (ctx.bn_sums and FUSE_BN_SUMS and x_ss is not None and x_ss.dim() == 2 and x_ss.shape[0] == 4
+                and Cc % (8 if x.dtype == torch.bfloat16 else 4) == 0)
+        sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device) if want else None
+        ws = workspace(query("mis_sum_gradients_workspace_bytes", Cc), x.device) if want else None
+        es = x.element_size()
+        with _prof("sum_gradients", 0, (len(gs) + 1 + (1 if want else 0)) * x.numel() * es):
+            call("mis_sum_gradients", _ptr_array(gs), len(gs), _dt(x), B * H * W, Cc, x.data_ptr() if want else None,
+                 _p(x_ss) if want else None, out.data_ptr(), _p(sums), _p(ws), _stream())
+        if want:
+            attach_bn_sums(out, sums, x)
+        return out, None, None, None
+
+
+FUSE_FAN_OUT = True      # (module attribute: the tests compare with autograd's own pairwise accumulation)
+
+
+def fan_out(x, x_ss, n, bn_sums=True):
+    """n aliases of the activation (x, x_ss) for n consumers; see FanOutFn."""
+    if n <= 1 or not FUSE_FAN_OUT or not (torch.is_grad_enabled() and x.requires_grad):
+        return [x] * n
+    return list(FanOutFn.apply(x, x_ss, n, bn_sums))
 
 
 class AmsfnFuseFn(torch.autograd.Function):

@@ -63,17 +63,23 @@ class A_UNet(nn.Module):
             raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
         pool, noise, up = F_.MaxPool2x2Fn.apply, F_.dropout2d_noise, UNet._up
         x = F_.to_act(x, self._dtype())
-        e1 = self.encoder1.forward_lazy(x)
-        a = self.acpn0.forward_lazy(*e1)
-        e2 = self.encoder2.forward_lazy(pool(*a, noise(self.encoder_dropout1, a[0])))
-        a = self.acpn1.forward_lazy(*e2)
-        e3 = self.encoder3.forward_lazy(pool(*a, noise(self.encoder_dropout2, a[0])))
-        a = self.acpn2.forward_lazy(*e3)
-        e4 = self.encoder4.forward_lazy(pool(*a, noise(self.encoder_dropout3, a[0])))
-        a = self.acpn3.forward_lazy(*e4)
+        # an encoder output is read by its AMSFN block and by the decoder's skip connection: two aliases whose
+        # gradients meet in one kernel (which also emits the encoder layer's BatchNorm-backward sums)
+        def two(e):
+            a, b = F_.fan_out(e[0], e[1], 2)
+            return (a, e[1]), (b, e[1])
+
+        e1, s1 = two(self.encoder1.forward_lazy(x))
+        a = self.acpn0.forward_lazy(*e1, input_read_elsewhere=True)
+        e2, s2 = two(self.encoder2.forward_lazy(pool(*a, noise(self.encoder_dropout1, a[0]))))
+        a = self.acpn1.forward_lazy(*e2, input_read_elsewhere=True)
+        e3, s3 = two(self.encoder3.forward_lazy(pool(*a, noise(self.encoder_dropout2, a[0]))))
+        a = self.acpn2.forward_lazy(*e3, input_read_elsewhere=True)
+        e4, s4 = two(self.encoder4.forward_lazy(pool(*a, noise(self.encoder_dropout3, a[0]))))
+        a = self.acpn3.forward_lazy(*e4, input_read_elsewhere=True)
         c5 = self.center_conv.forward_lazy(pool(*a, noise(self.encoder_dropout4, a[0])))
-        d = self.acpn5.forward_lazy(*up(self.decoder1, *c5, *e4, noise(self.bottleneck_dropout, c5[0])))
-        d = self.acpn6.forward_lazy(*up(self.decoder2, *d, *e3, noise(self.decoder_dropout1, d[0])))
-        d = self.acpn7.forward_lazy(*up(self.decoder3, *d, *e2, noise(self.decoder_dropout2, d[0])))
-        d = self.acpn8.forward_lazy(*up(self.decoder4, *d, *e1, None))
+        d = self.acpn5.forward_lazy(*up(self.decoder1, *c5, *s4, noise(self.bottleneck_dropout, c5[0])))
+        d = self.acpn6.forward_lazy(*up(self.decoder2, *d, *s3, noise(self.decoder_dropout1, d[0])))
+        d = self.acpn7.forward_lazy(*up(self.decoder3, *d, *s2, noise(self.decoder_dropout2, d[0])))
+        d = self.acpn8.forward_lazy(*up(self.decoder4, *d, *s1, None))
         return F_.materialize(*self.out_conv.forward_lazy(*d))

@@ -109,14 +109,17 @@ class AMSFN(nn.Module):
             x, x_ss = F_.conv_bn_relu_w(x, x_ss, W, b, seq[i + 1], self.training)
         return x, x_ss
 
-    def forward_lazy(self, x, x_ss=None):
-        """(x, x_ss) lazy or plain activation -> lazy (z, ss) of the final conv."""
-        pooled = F_.MaxPool3x3Fn.apply(x, x_ss)
+    def forward_lazy(self, x, x_ss=None, input_read_elsewhere=False):
+        """(x, x_ss) lazy or plain activation -> lazy (z, ss) of the final conv.  The input feeds four branches:
+        their gradients are summed in one kernel (functional.fan_out), which also produces the BatchNorm-backward
+        sums of the layer that wrote x unless the caller says that x has further readers."""
+        x1, x2, x3, x4 = F_.fan_out(x, x_ss, 4, bn_sums=not input_read_elsewhere)
+        pooled = F_.MaxPool3x3Fn.apply(x1, x_ss)
         c1 = F_.conv_bn_relu_w(pooled, None, F_.pointwise_as_3x3(self.conv1x1[1].weight), self.conv1x1[1].bias,
                                self.conv1x1[2], self.training)
-        c2 = self._dw_chain(self.cbr1, x, x_ss)
-        c3 = self._dw_chain(self.cbr2, x, x_ss)
-        c4 = self._dw_chain(self.cbr3, x, x_ss)
+        c2 = self._dw_chain(self.cbr1, x2, x_ss)
+        c3 = self._dw_chain(self.cbr2, x3, x_ss)
+        c4 = self._dw_chain(self.cbr3, x4, x_ss)
         fused = F_.AmsfnFuseFn.apply(*c1, *c2, *c3, *c4, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
                                      self.mlp[2].bias)
         return F_.conv_bn_relu_w(fused, None, F_.pointwise_as_3x3(self.final_conv[0].weight),

@@ -45,6 +45,40 @@ def test_maxpool3x3_matches_torch():
         assert rel_err(xd.grad, xr.grad) < (1e-6 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 9, 13), (1, 16, 1, 7), (3, 8, 2, 1), (1, 32, 16, 5), (2, 6, 7, 3), (1, 8, 4, 4),
+                                   (1, 8, 33, 18)])
+@pytest.mark.parametrize("lazy", [False, True])
+def test_maxpool3x3_row_strips(dtype, shape, lazy):
+    """Heights around the 4-row strips a thread owns (1, 2, 4, 7, 9, 16, 33), a lazy input with scales of both
+    signs (values and window positions are those of the rounded activation), NaNs (maximal; the gradient goes to
+    one of them) and ties: values equal torch's max_pool2d bit for bit, gradients to rounding."""
+    from medical_image_segmentation_amd import functional as F_
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H * 100 + W)
+    z = torch.randint(-3, 4, shape, generator=g).float() * 0.5
+    ss = None
+    if lazy:
+        scale = torch.tensor([(-1.0) ** c * (0.5 + 0.25 * (c % 3)) for c in range(C)])
+        shift = torch.tensor([0.25 * ((c % 5) - 2) for c in range(C)])
+        ss = torch.stack([scale, shift]).to(DEV)
+        a = torch.relu(z.to(dtype).float() * scale[None, :, None, None] + shift[None, :, None, None]).to(dtype).float()
+    else:
+        if H * W > 4:
+            z[0, 0, H // 2, W // 2] = float("nan")
+            z[-1, -1, 0, 0] = float("nan")
+        a = z.to(dtype).float()
+    gy = torch.randn(shape, generator=g).to(dtype)
+    zd = z.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = F_.MaxPool3x3Fn.apply(zd, ss)
+    y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+    ar = a.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(ar, 3, 1, 1)
+    yr.backward(gy.float())
+    assert torch.equal(y.float().cpu().nan_to_num(nan=1234.0), yr.detach().nan_to_num(nan=1234.0))
+    assert rel_err(zd.grad, ar.grad) < (1e-6 if dtype == torch.float32 else 1e-2)   # gradient w.r.t. the activation
+
+
 def test_amsfn_block_golden(golden):
     from medical_image_segmentation_amd.model.utils.modules import AMSFN
     g = golden("a_unet")

@@ -365,7 +365,9 @@ CBR_SHAPES = [(2, 1, 8, 16, 16), (2, 3, 8, 16, 16), (2, 8, 32, 16, 16), (1, 32, 
               (2, 16, 64, 8, 8), (1, 64, 8, 32, 32), (2, 24, 8, 8, 8),
               # image-facing layer across its 16x64 LDS tiles: ragged edges, several tiles per
               # workgroup, two channel slices, a channel count without 16-byte stores
-              (1, 1, 8, 37, 70), (2, 3, 12, 19, 130), (1, 1, 16, 100, 64), (3, 1, 8, 48, 200)]
+              (1, 1, 8, 37, 70), (2, 3, 12, 19, 130), (1, 1, 16, 100, 64), (3, 1, 8, 48, 200),
+              # narrow outputs: 1, 2, 3 (padded to 4) and 4 channels per thread of the direct kernel
+              (2, 32, 1, 16, 16), (1, 16, 2, 24, 40), (2, 32, 3, 16, 24), (1, 8, 4, 19, 33), (2, 5, 1, 9, 11)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

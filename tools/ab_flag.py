@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of a boolean switch of medical_image_segmentation_amd.functional inside one process:
-alternating blocks of timed bench-shaped steps.   python tools/ab_flag.py FUSE_POOL_DZ [batch]"""
+"""A/B of a switch of medical_image_segmentation_amd.functional inside one process: alternating blocks of
+timed bench-shaped steps.   python tools/ab_flag.py FLAG [batch] [unet|a_unet|rdam_unet] [valueA valueB]
+(values are Python literals; default False True)"""
+import ast
 import os
 import sys
 import time
@@ -9,15 +11,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from medical_image_segmentation_amd import functional as F_  # noqa: E402
 from medical_image_segmentation_amd.model.unet import UNet  # noqa: E402
+from medical_image_segmentation_amd.model.a_unet import A_UNet  # noqa: E402
+from medical_image_segmentation_amd.model.rdam_unet import RDAM_UNet  # noqa: E402
 from medical_image_segmentation_amd.utils.loss_fn import diceloss  # noqa: E402
 from medical_image_segmentation_amd.utils.optim import clip_and_step  # noqa: E402
 
 flag = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dev = torch.device("cuda", 0)
-m = UNet(1, 4, 0, base_channels=32, compute_dtype=torch.bfloat16).to(dev).train()
+net, cin = {"unet": (UNet, 1), "a_unet": (A_UNet, 3), "rdam_unet": (RDAM_UNet, 3)}[sys.argv[3] if len(sys.argv) > 3 else "unet"]
+m = net(cin, 4, 0, base_channels=32, compute_dtype=torch.bfloat16).to(dev).train()
 opt = torch.optim.AdamW(m.parameters(), lr=8e-4, betas=(0.95, 0.999), weight_decay=1e-4)
-x = torch.randn(B, 1, 512, 512, device=dev)
+x = torch.randn(B, cin, 512, 512, device=dev)
 y = torch.randint(0, 4, (B, 512, 512), device=dev)
 loss_fn = diceloss(["a", "b", "c"])
 params = list(m.parameters())
@@ -29,7 +34,8 @@ def step():
     clip_and_step(opt, params, 1.0)
 
 
-for value in (False, True, False, True, False, True):
+va, vb = (ast.literal_eval(sys.argv[4]), ast.literal_eval(sys.argv[5])) if len(sys.argv) > 5 else (False, True)
+for value in (va, vb, va, vb, va, vb):
     setattr(F_, flag, value)
     for _ in range(5):
         step()
