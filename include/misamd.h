@@ -354,6 +354,14 @@ int mis_bn_relu_bwd_dz(const void* z, const void* da, int dtype, int64_t n_pix, 
 int mis_bn_relu_bwd_dz_head(const void* z, const void* head_dy, const float* head_w, int head_cout, int dtype,
                             int64_t n_pix, int C, const float* mean_rstd, const float* gamma, const float* beta,
                             const float* sums, void* dz, float* dbias, void* workspace, mis_stream_t stream);
+/* Pass 2 for a branch layer of the AMSFN fusion (modules.py:846-868): the incoming  */
+/* gradient is da[p][c] = g[p][c]*g_scale[b][c] + g_shift[b][c] (b = p / hw; tables    */
+/* float32 with row stride coef_ld), formed on load in float32 from the fusion's      */
+/* output gradient g; `sums` come from mis_amsfn_fuse_bwd_lazy.  n_pix < 2^31.         */
+int mis_bn_relu_bwd_dz_scaled(const void* z, const void* g, const float* g_scale, const float* g_shift, int coef_ld,
+                              int64_t hw, int dtype, int64_t n_pix, int C, const float* mean_rstd, const float* gamma,
+                              const float* beta, const float* sums, void* dz, float* dbias, void* workspace,
+                              mis_stream_t stream);
 /* The same two passes for a BatchNorm2d that is NOT followed by a ReLU of its own  */
 /* (ResDConv's `c1` and `cbr3`, model/utils/modules.py:432-433,444-445): dy is the    */
 /* gradient of the BatchNorm output as it is, no mask.                               */
@@ -429,6 +437,21 @@ int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const
                        int C, const float* W1, const float* W2, const float* s, const float* h, const float* w,
                        void* const* dact, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
                        mis_stream_t stream);
+/* The same backward (modules.py:846-868 under autograd) when every branch is the    */
+/* lazy output of a training-mode conv + BatchNorm + ReLU layer (z_affine4[k] is its   */
+/* [4][C] table scale, shift, mean, rstd; bn_gamma / bn_beta [k] its BatchNorm          */
+/* parameters): the four gradients dact[k] = dout*w_k + ds_k/HW are NOT written.        */
+/* Returned instead: dact_shift [B][4C] = ds/HW (with w, the two tables that turn dout  */
+/* into dact[k] — consumed by mis_bn_relu_bwd_dz_scaled) and bn_sums [4][2][C] =         */
+/* (sum dy, sum dy*xhat) of each branch layer's BatchNorm backward, collected in the     */
+/* same pass over (dout, z_k) that forms the fusion-weight gradient.  Workspace:         */
+/* mis_amsfn_lazy_workspace_bytes.                                                       */
+size_t mis_amsfn_lazy_workspace_bytes(int B, int HW, int C);
+int mis_amsfn_fuse_bwd_lazy(const void* const* z, const float* const* z_affine4, const float* const* bn_gamma,
+                            const float* const* bn_beta, const void* dout, int dtype, int B, int HW, int C,
+                            const float* W1, const float* W2, const float* s, const float* h, const float* w,
+                            float* bn_sums, float* dact_shift, float* dW1, float* db1, float* dW2, float* db2,
+                            void* workspace, mis_stream_t stream);
 
 /* DWConv (modules.py:52-60) = pointwise 1x1 after depthwise 3x3 is one dense 3x3    */
 /* conv: W[o][i][3][3] = P[o][i] * D[i][3][3], b[o] = bp[o] + sum_i P[o][i]*bd[i]      */

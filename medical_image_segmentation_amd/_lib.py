@@ -73,6 +73,7 @@ PROTOTYPES = {
     "mis_bn_relu_bwd_dz_rows": (_i, [_i, _i64, _i]),
     "mis_bn_relu_bwd_dz_head": (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_relu_bwd_dz_scaled": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_add_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
@@ -93,6 +94,9 @@ PROTOTYPES = {
     "mis_sum_gradients_workspace_bytes": (_sz, [_i]),
     "mis_sum_gradients": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_amsfn_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mis_amsfn_lazy_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mis_amsfn_fuse_bwd_lazy": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp]),
     "mis_amsfn_fuse_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_amsfn_fuse_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp]),

@@ -364,6 +364,116 @@ __global__ __launch_bounds__(TPB) void wsum_bwd_dact_kernel(const T* __restrict_
   }
 }
 
+// ---- backward without the four branch gradients in memory -----------------------------------------
+// The gradient of branch k is da_k = dout * w[b][k][c] + ds[b][k][c] / HW: one tensor (dout) and two small
+// per-(sample, channel) tables.  The BatchNorm layer that produced the branch needs sum(dy) and sum(dy*xhat)
+// of dy = da_k*[y > 0]; both are linear in the tables, so ONE pass over (dout, z_k) that runs BEFORE ds is
+// known collects, per (sample, branch, channel),
+//   q0 = sum a*g (the gradient of the fusion weights),  q1 = sum [y>0]*g,  q2 = sum [y>0]*g*xhat,
+//   q3 = sum [y>0],  q4 = sum [y>0]*xhat,
+// and a small kernel combines them after the squeeze MLP's backward:
+//   sum dy = sum_b (w*q1 + ds/HW*q3),   sum dy*xhat = sum_b (w*q2 + ds/HW*q4).
+// The branch layers then form da_k on the fly in their dz kernel (bn.hip, scaled mode); the four gradient
+// tensors are neither written nor read, and their four reduction passes disappear.
+struct BranchBn {
+  const float* gamma[4];   // [C] each; mean and rstd are rows 2 and 3 of the branch's [4][C] affine
+  const float* beta[4];
+};
+constexpr int ST_N = 5;
+
+// Workgroup = (branch k, sample b, pixel chunk r); thread = (channel vector cv, pixel lane pl) walking a
+// contiguous chunk.  partials[r][q][b][k*C + c]; fixed-order LDS tree.
+template <typename T, int V>
+__global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn bn, const T* __restrict__ g, int B,
+                                                           int HW, int C, int rows, int chunk,
+                                                           float* __restrict__ partials) {
+  extern __shared__ float red[];             // [PL][ST_N][C]
+  const int CV = C / V, PL = TPB / CV;
+  const int k = blockIdx.x & 3, r = (blockIdx.x >> 2) % rows, b = (blockIdx.x >> 2) / rows;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, c0 = cv * V;
+  const float* aff = br.aff[k];              // [4][C]: scale, shift, mean, rstd
+  float acc[ST_N][V];
+#pragma unroll
+  for (int q = 0; q < ST_N; q++)
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[q][j] = 0.f;
+  if (pl < PL) {
+    float sc[V], sh[V], mu[V], rs[V], ga[V], be[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      sc[j] = aff[c0 + j];
+      sh[j] = aff[C + c0 + j];
+      mu[j] = aff[2 * C + c0 + j];
+      rs[j] = aff[3 * C + c0 + j];
+      ga[j] = bn.gamma[k][c0 + j];
+      be[j] = bn.beta[k][c0 + j];
+    }
+    const T* zk = (const T*)br.z[k];
+    const int p1 = (r + 1) * chunk < HW ? (r + 1) * chunk : HW;
+#pragma unroll 2
+    for (int p = r * chunk + pl; p < p1; p += PL) {
+      const int64_t idx = ((int64_t)b * HW + p) * C + c0;
+      float gv[V], zv[V];
+      vload<T, V>(g + idx, gv);
+      vload<T, V>(zk + idx, zv);
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        const float a = to_f32(from_f32<T>(fmaxf(zv[j] * sc[j] + sh[j], 0.f)));      // the activation as consumers read it
+        const float xh = (zv[j] - mu[j]) * rs[j];
+        const bool on = xh * ga[j] + be[j] > 0.f;                                    // the mask of the layer's dz kernel
+        const float dy = on ? gv[j] : 0.f;
+        acc[0][j] += a * gv[j];
+        acc[1][j] += dy;
+        acc[2][j] += dy * xh;
+        acc[3][j] += on ? 1.f : 0.f;
+        acc[4][j] += on ? xh : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < ST_N; q++)
+#pragma unroll
+      for (int j = 0; j < V; j++) red[(pl * ST_N + q) * C + c0 + j] = acc[q][j];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ST_N * C; e += TPB) {
+    float t = 0.f;
+    for (int q = 0; q < PL; q++) t += red[q * ST_N * C + e];
+    const int qq = e / C, c = e % C;
+    partials[(((int64_t)r * ST_N + qq) * B + b) * 4 * C + k * C + c] = t;
+  }
+}
+
+// stats [ST_N][B][4C] (+ w, ds [B][4C]) -> bn_sums [4][2][C] and the shift table ds/HW [B][4C]
+__global__ __launch_bounds__(TPB) void branch_bn_sums_kernel(const float* __restrict__ stats, const float* __restrict__ w,
+                                                             const float* __restrict__ ds, float inv, int B, int C,
+                                                             float* __restrict__ bn_sums, float* __restrict__ shift) {
+  const int C4 = 4 * C;
+  const int64_t plane = (int64_t)B * C4;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < C4; j += gridDim.x * TPB) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < B; b++) {
+      const int64_t i = (int64_t)b * C4 + j;
+      const float wk = w[i], sk = ds[i] * inv;
+      shift[i] = sk;
+      s1 += (double)wk * stats[plane + i] + (double)sk * stats[3 * plane + i];
+      s2 += (double)wk * stats[2 * plane + i] + (double)sk * stats[4 * plane + i];
+    }
+    const int k = j / C, c = j % C;
+    bn_sums[(k * 2 + 0) * C + c] = (float)s1;
+    bn_sums[(k * 2 + 1) * C + c] = (float)s2;
+  }
+}
+
+// pixel chunks per (sample, branch): >= 16 pixels per thread, about 8192 workgroups at most
+inline int stats_rows(int B, int HW, int C, int V) {
+  const int PL = TPB / (C / V);
+  int rows = HW / (PL * 16);
+  const int cap = (8192 + 4 * B - 1) / (4 * B);
+  if (rows > cap) rows = cap;
+  if (rows < 1) rows = 1;
+  return rows;
+}
+
 // pixel rows of the two reductions: enough workgroups to fill the chip, >= 8 pixels per thread
 inline int dot_rows(int B, int HW, int C, int V) {
   const int PL = TPB / (C / V);
@@ -405,16 +515,17 @@ __global__ __launch_bounds__(TPB) void dw_compose_bwd_kernel(const float* __rest
   // dP: one thread per element (9 terms).  dD and dbd sum over Cout: 8 consecutive lanes share an
   // element (lane j takes o = j, j+8, ...) and are summed on the DPP path, so the dependent chain is
   // Cout/8 long instead of Cout.  TPB is a multiple of 8 and the grid-stride keeps lane groups whole.
-  const int nP = Cout * Cin, nD = Cin * 9;
-  const int total = nP + 8 * (nD + Cin);
+  // (the 8-lane groups start at a multiple of 8, so that a group is one aligned lane octet of a wave)
+  const int nP = Cout * Cin, nP8 = (nP + 7) & ~7, nD = Cin * 9;
+  const int total = nP8 + 8 * (nD + Cin);
   for (int e = blockIdx.x * TPB + threadIdx.x; e < total; e += gridDim.x * TPB) {
     float acc = 0.f;
     if (e < nP) {
       const int i = e % Cin, o = e / Cin;
       for (int t = 0; t < 9; t++) acc += dW[(o * Cin + i) * 9 + t] * D[i * 9 + t];
       dP[e] = acc + db[o] * bd[i];
-    } else {
-      const int g = (e - nP) >> 3, j = (e - nP) & 7;
+    } else if (e >= nP8) {
+      const int g = (e - nP8) >> 3, j = (e - nP8) & 7;
       if (g < nD) {
         const int t = g % 9, i = g / 9;
         for (int o = j; o < Cout; o += 8) acc += dW[(o * Cin + i) * 9 + t] * P[o * Cin + i];
@@ -565,6 +676,38 @@ int fuse_bwd_t(const Branches& br, const Grads& gr, const void* dout, int B, int
   return MIS_OK;
 }
 
+
+template <typename T>
+int fuse_bwd_lazy_t(const Branches& br, const BranchBn& bn, const void* dout, int B, int HW, int C, const float* W1,
+                    const float* W2, const float* s, const float* h, const float* w, float* bn_sums, float* shift,
+                    float* dW1, float* db1, float* dW2, float* db2, void* workspace, hipStream_t st) {
+  const int C4 = 4 * C;
+  const int V = fuse_vec<T>(C, br, dout, nullptr);
+  const int rows = stats_rows(B, HW, C, V), chunk = (HW + rows - 1) / rows;
+  // workspace: partial rows [rows][ST_N][B][4C] | stats [ST_N][B][4C] (plane 0 = dw) | g2 | ds [B][4C] | g1 [B][C]
+  const size_t vec = align256((size_t)B * C4 * sizeof(float));
+  float* partials = (float*)workspace;
+  float* stats = (float*)((char*)workspace + align256((size_t)rows * ST_N * B * C4 * sizeof(float)));
+  float* g2 = (float*)((char*)stats + align256((size_t)ST_N * B * C4 * sizeof(float)));
+  float* ds = (float*)((char*)g2 + vec);
+  float* g1 = (float*)((char*)ds + vec);
+  const size_t lds = (size_t)(TPB / (C / V)) * ST_N * C * sizeof(float);
+  if (V == VecOf<T>::N)
+    branch_stats_kernel<T, VecOf<T>::N><<<4 * B * rows, TPB, lds, st>>>(br, bn, (const T*)dout, B, HW, C, rows, chunk, partials);
+  else
+    branch_stats_kernel<T, 1><<<4 * B * rows, TPB, lds, st>>>(br, bn, (const T*)dout, B, HW, C, rows, chunk, partials);
+  MIS_CHECK_LAUNCH("branch_stats_kernel");
+  launch_reduce_partials(partials, rows, ST_N * B * C4, stats, st);
+  MIS_CHECK_LAUNCH("reduce_partials_kernel");
+  mlp_bwd_sample_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(stats, w, h, W1, W2, C, g1, g2, ds);
+  MIS_CHECK_LAUNCH("mlp_bwd_sample_kernel");
+  branch_bn_sums_kernel<<<cdiv(C4, TPB), TPB, 0, st>>>(stats, w, ds, 1.0f / (float)HW, B, C, bn_sums, shift);
+  MIS_CHECK_LAUNCH("branch_bn_sums_kernel");
+  const int64_t np = 2 * (int64_t)C * C4 + C + C4;
+  mlp_bwd_param_kernel<<<ew_grid(np, TPB), TPB, 0, st>>>(g1, g2, s, h, B, C, dW1, db1, dW2, db2);
+  MIS_CHECK_LAUNCH("mlp_bwd_param_kernel");
+  return MIS_OK;
+}
 
 // ---- several consumers of one activation: their gradients summed in ONE pass ----------------------
 // out = g0 + g1 (+ g2 + g3 + g4), added in float32 in slot order and rounded once.  When the activation is
@@ -720,6 +863,40 @@ int mis_amsfn_fuse_bwd(const void* const* z, const float* const* z_affine, const
                            (hipStream_t)stream);
 }
 
+size_t mis_amsfn_lazy_workspace_bytes(int B, int HW, int C) {
+  if (B < 1 || HW < 1 || C < 1) return 0;
+  const int rows = stats_rows(B, HW, C, 1) > stats_rows(B, HW, C, 4) ? stats_rows(B, HW, C, 1) : stats_rows(B, HW, C, 4);
+  const size_t plane = (size_t)B * 4 * C * sizeof(float);
+  return align256((size_t)rows * ST_N * plane) + align256(ST_N * plane) + 3 * align256(plane);
+}
+
+int mis_amsfn_fuse_bwd_lazy(const void* const* z, const float* const* z_affine4, const float* const* bn_gamma,
+                            const float* const* bn_beta, const void* dout, int dtype, int B, int HW, int C,
+                            const float* W1, const float* W2, const float* s, const float* h, const float* w,
+                            float* bn_sums, float* dact_shift, float* dW1, float* db1, float* dW2, float* db2,
+                            void* workspace, mis_stream_t stream) {
+  MIS_REQUIRE(z && z_affine4 && bn_gamma && bn_beta && dout && W1 && W2 && s && h && w && bn_sums && dact_shift && dW1 &&
+                  db1 && dW2 && db2 && workspace,
+              "amsfn_fuse_bwd_lazy: null pointer");
+  MIS_REQUIRE(B >= 1 && HW >= 1 && C >= 1 && C <= TPB, "amsfn_fuse_bwd_lazy: need 1 <= C <= %d (C=%d)", TPB, C);
+  MIS_REQUIRE((int64_t)B * HW < ((int64_t)1 << 31), "amsfn_fuse_bwd_lazy: too many pixels");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "amsfn_fuse_bwd_lazy: bad dtype %d", dtype);
+  Branches br;
+  BranchBn bn;
+  for (int k = 0; k < 4; k++) {
+    MIS_REQUIRE(z[k] && z_affine4[k] && bn_gamma[k] && bn_beta[k], "amsfn_fuse_bwd_lazy: null branch %d", k);
+    br.z[k] = z[k];
+    br.aff[k] = z_affine4[k];
+    bn.gamma[k] = bn_gamma[k];
+    bn.beta[k] = bn_beta[k];
+  }
+  if (dtype == MIS_BF16)
+    return fuse_bwd_lazy_t<bf16>(br, bn, dout, B, HW, C, W1, W2, s, h, w, bn_sums, dact_shift, dW1, db1, dW2, db2,
+                                 workspace, (hipStream_t)stream);
+  return fuse_bwd_lazy_t<float>(br, bn, dout, B, HW, C, W1, W2, s, h, w, bn_sums, dact_shift, dW1, db1, dW2, db2,
+                                workspace, (hipStream_t)stream);
+}
+
 size_t mis_sum_gradients_workspace_bytes(int C) {
   return C >= 1 ? align256((size_t)SUM_MAX_ROWS * 2 * C * sizeof(float)) + 256 : 0;
 }
@@ -758,7 +935,7 @@ int mis_dwconv_compose_bwd(const float* P, const float* D, const float* bd, cons
                            int Cin, float* dP, float* dD, float* dbd, mis_stream_t stream) {
   MIS_REQUIRE(P && D && bd && dW && db && dP && dD && dbd, "dwconv_compose_bwd: null pointer");
   MIS_REQUIRE(Cout >= 1 && Cin >= 1 && (int64_t)Cout * Cin * 9 < (1 << 30), "dwconv_compose_bwd: bad shape");
-  dw_compose_bwd_kernel<<<ew_grid((int64_t)Cout * Cin + Cin * 80, TPB), TPB, 0, (hipStream_t)stream>>>(
+  dw_compose_bwd_kernel<<<ew_grid((int64_t)Cout * Cin + 8 + Cin * 80, TPB), TPB, 0, (hipStream_t)stream>>>(
       P, D, bd, dW, db, Cout, Cin, dP, dD, dbd);
   MIS_CHECK_LAUNCH("dw_compose_bwd_kernel");
   return MIS_OK;

@@ -207,8 +207,11 @@ struct ChannelSum {
 // formed here from that conv's output gradient head_dy [pixel][head_co] and its weights head_w
 // [head_co][C] — da[c] = sum_j dy[j]*w[j][c], rounded to T exactly as the 1x1 backward kernel
 // would have stored it — so that tensor is neither written nor read.
+// SCALED: the incoming gradient is da = g * g_scale[b][c] + g_shift[b][c] with per-(sample, channel) tables
+// (the backward of a per-sample weighted sum plus a global average pool: the AMSFN fusion): formed on load
+// in float32, so no per-branch gradient tensor exists.  `head_w` carries g_scale.
 constexpr int HEAD_MAX_CO = 8;
-template <typename T, int V, bool HEAD = false, int HCO = HEAD_MAX_CO>
+template <typename T, int V, bool HEAD = false, int HCO = HEAD_MAX_CO, bool SCALED = false>
 __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __restrict__ z, const T* __restrict__ da,
                                                                     T* __restrict__ dz, int64_t n_vec, int C,
                                                                     float inv_n, const float* __restrict__ mean_rstd,
@@ -217,7 +220,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
                                                                     const float* __restrict__ sums,
                                                                     float* __restrict__ dz_partials, int relu,
                                                                     const float* __restrict__ head_w = nullptr,
-                                                                    int head_co = 0) {
+                                                                    int head_co = 0,
+                                                                    const float* __restrict__ g_shift = nullptr,
+                                                                    int coef_ld = 0, unsigned px_per_sample = 1) {
   extern __shared__ float prm[];   // scratch for the optional bias partial: [256][V]
   const int CV = C / V;
   const int64_t i0 = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -274,6 +279,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
       for (int k = 0; k < V; k++) gv[k] = to_f32(from_f32<T>(gv[k]));
     } else {
       vload<T, V>(da + i * V, gv);
+      if constexpr (SCALED) {
+        // (32-bit: the host checks the pixel count; a thread keeps its channel vector, so only the sample moves)
+        const int64_t row = (int64_t)((unsigned)pix / px_per_sample) * coef_ld + c0;
+#pragma unroll
+        for (int k = 0; k < V; k++) gv[k] = gv[k] * head_w[row + k] + g_shift[row + k];
+      }
     }
 #pragma unroll
     for (int k = 0; k < V; k++) {
@@ -338,16 +349,25 @@ static inline int bwd_dz_grid(int64_t n, int C, int V) {
 template <typename T>
 int bwd_dz_t(const void* z, const void* da, void* dz, int64_t n_pix, int C, const float* mean_rstd,
              const float* gamma, const float* beta, const float* sums, float* dbias, void* ws, hipStream_t st,
-             int relu, const float* head_w = nullptr, int head_co = 0) {
+             int relu, const float* head_w = nullptr, int head_co = 0, const float* g_shift = nullptr,
+             int coef_ld = 0, int64_t hw = 0) {
   constexpr int N = VecOf<T>::N;
   const int64_t n = n_pix * C;
   const size_t lds = (size_t)EW_THREADS * N * sizeof(float);
   const float inv_n = (float)(1.0 / (double)n_pix);
-  const bool vec = (head_w ? pick_vec<T>(C, z, dz) : pick_vec<T>(C, z, da, dz)) == N;
+  const bool vec = ((head_w && !g_shift) ? pick_vec<T>(C, z, dz) : pick_vec<T>(C, z, da, dz)) == N;
   const int V = vec ? N : 1;
   const int grid = bwd_dz_grid(n, C, V);
   float* partials = dbias ? (float*)ws : nullptr;
-  if (head_w && vec && head_co <= 4)
+  if (g_shift && vec)
+    bn_relu_bwd_dz_kernel<T, N, false, HEAD_MAX_CO, true><<<grid, EW_THREADS, lds, st>>>(
+        (const T*)z, (const T*)da, (T*)dz, n / N, C, inv_n, mean_rstd, gamma, beta, sums, partials, relu, head_w, 0,
+        g_shift, coef_ld, (unsigned)hw);
+  else if (g_shift)
+    bn_relu_bwd_dz_kernel<T, 1, false, HEAD_MAX_CO, true><<<grid, EW_THREADS, lds, st>>>(
+        (const T*)z, (const T*)da, (T*)dz, n, C, inv_n, mean_rstd, gamma, beta, sums, partials, relu, head_w, 0, g_shift,
+        coef_ld, (unsigned)hw);
+  else if (head_w && vec && head_co <= 4)
     bn_relu_bwd_dz_kernel<T, N, true, 4><<<grid, EW_THREADS, lds, st>>>((const T*)z, (const T*)da, (T*)dz, n / N, C,
                                                                           inv_n, mean_rstd, gamma, beta, sums, partials,
                                                                           relu, head_w, head_co);
@@ -461,7 +481,7 @@ int mis_bn_bwd_reduce(const void* z, const void* dy, int dtype, int64_t n_pix, i
 static int bn_bwd_dz_any(const void* z, const void* da, int dtype, int64_t n_pix, int C, const float* mean_rstd,
                          const float* gamma, const float* beta, const float* sums, void* dz, float* dbias,
                          void* workspace, mis_stream_t stream, int relu, const float* head_w = nullptr,
-                         int head_co = 0) {
+                         int head_co = 0, const float* g_shift = nullptr, int coef_ld = 0, int64_t hw = 0) {
   MIS_REQUIRE(z && da && mean_rstd && gamma && beta && sums && dz, "bn_relu_bwd_dz: null pointer");
   MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_dz: bad shape");
   MIS_REQUIRE(!dbias || workspace, "bn_relu_bwd_dz: dbias requested without a workspace");
@@ -470,10 +490,10 @@ static int bn_bwd_dz_any(const void* z, const void* da, int dtype, int64_t n_pix
               "bn_relu_bwd_dz: partial rows need 16-byte aligned tensors");
   if (dtype == MIS_F32)
     bwd_dz_t<float>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream, relu,
-                    head_w, head_co);
+                    head_w, head_co, g_shift, coef_ld, hw);
   else if (dtype == MIS_BF16)
     bwd_dz_t<bf16>(z, da, dz, n_pix, C, mean_rstd, gamma, beta, sums, dbias, workspace, (hipStream_t)stream, relu,
-                   head_w, head_co);
+                   head_w, head_co, g_shift, coef_ld, hw);
   else MIS_REQUIRE(false, "bn_relu_bwd_dz: bad dtype %d", dtype);
   MIS_CHECK_LAUNCH("bn_relu_bwd_dz_kernel");
   return MIS_OK;
@@ -492,6 +512,17 @@ int mis_bn_relu_bwd_dz_head(const void* z, const void* head_dy, const float* hea
               HEAD_MAX_CO);
   return bn_bwd_dz_any(z, head_dy, dtype, n_pix, C, mean_rstd, gamma, beta, sums, dz, dbias, workspace, stream, 1, head_w,
                        head_cout);
+}
+
+int mis_bn_relu_bwd_dz_scaled(const void* z, const void* g, const float* g_scale, const float* g_shift, int coef_ld,
+                              int64_t hw, int dtype, int64_t n_pix, int C, const float* mean_rstd, const float* gamma,
+                              const float* beta, const float* sums, void* dz, float* dbias, void* workspace,
+                              mis_stream_t stream) {
+  MIS_REQUIRE(g_scale && g_shift && coef_ld >= C, "bn_relu_bwd_dz_scaled: need both tables, row stride >= C");
+  MIS_REQUIRE(hw >= 1 && n_pix % hw == 0 && n_pix < ((int64_t)1 << 31),
+              "bn_relu_bwd_dz_scaled: n_pix must be a whole number of samples of hw pixels, below 2^31");
+  return bn_bwd_dz_any(z, g, dtype, n_pix, C, mean_rstd, gamma, beta, sums, dz, dbias, workspace, stream, 1, g_scale, 0,
+                       g_shift, coef_ld, hw);
 }
 
 int mis_bn_bwd_dz(const void* z, const void* dy, int dtype, int64_t n_pix, int C, const float* mean_rstd,

@@ -623,7 +623,10 @@ def _wants_bn_sums(x_ss, numel):
             and numel >= BN_SUMS_MIN_NUMEL)
 
 
-DGRAD_BN_SUMS_MIN_PIXELS = 0     # per image: below this the data gradient leaves the sums to the layer's own pass
+# The matrix-core data gradient can also emit the sums (mis_conv3x3_dgrad_bn_sums).  Off: on the full step the conv's
+# longer epilogue costs more than the layer's own reduction pass, which reads a gradient that is still in the
+# memory-side cache (measured, one process, alternating blocks: U-Net 4.43 -> 4.35 ms, A_UNet 32.65 -> 32.06 ms).
+FUSE_DGRAD_BN_SUMS = False
 
 
 def _dgrad_with_bn_sums(dz, wd, x, x_ss):
@@ -635,7 +638,7 @@ def _dgrad_with_bn_sums(dz, wd, x, x_ss):
         return None
     B, Cout, H, W = x.shape                 # the data gradient produces x's channels
     Cin = dz.shape[1]
-    if H * W < DGRAD_BN_SUMS_MIN_PIXELS:
+    if not FUSE_DGRAD_BN_SUMS:
         return None
     if not query("mis_conv3x3_dgrad_bn_sums_supported", _dt(x), B, H, W, Cin, Cout):
         return None
@@ -664,6 +667,26 @@ class HeadFusion:
         self.ptr = self.version = -1
 
 
+class BranchGradLink:
+    """Couples a conv+BN+ReLU layer with the AMSFN fusion node that is the ONLY consumer of its output
+    (modules.py:846-868): pass one object as `link=` to the layer and in `links=` to AmsfnFuseFn.  The gradient of
+    a branch is dout * w_k + ds_k / HW — the fusion's output gradient and two per-(sample, channel) tables — so
+    in the backward pass the fusion writes no branch gradient: it leaves dout, the tables and the layer's
+    BatchNorm-backward sums here, and the layer's dz kernel forms the gradient on load
+    (mis_bn_relu_bwd_dz_scaled).  The tensor autograd hands the layer is dout itself, as a placeholder that
+    must arrive untouched: with another consumer of the branch autograd would add to it, and the layer's
+    backward raises."""
+    __slots__ = ("gamma", "beta", "g", "scale_ptr", "shift_ptr", "ld", "sums", "keep", "ptr", "version")
+
+    def __init__(self):
+        self.gamma = self.beta = self.g = self.sums = self.keep = None
+        self.scale_ptr = self.shift_ptr = self.ld = 0
+        self.ptr = self.version = -1
+
+
+FUSE_AMSFN_BWD = True    # (module attribute: the tests compare with the form that writes the four branch gradients)
+
+
 # Order of a layer's two backward convs: weight gradient first.  The data gradient is then the last kernel of the
 # layer, and what consumes its output — the next layer's BatchNorm backward, the upsampling or pooling backward —
 # runs right behind it, while that tensor is still in the memory-side cache (measured 4.50 -> 4.48 ms per step
@@ -679,7 +702,7 @@ class ConvBnReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x_ss, x2, x2_ss, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps,
-                momentum, relu=True, dilation=1, head=None):
+                momentum, relu=True, dilation=1, head=None, link=None):
         """x2 (optional, lazy or plain like x): the input is the virtual concatenation [x | x2].
         relu=False: BatchNorm without a ReLU of its own (ResDConv's `c1` and `cbr3`, modules.py:432-433,
         444-445): ss is then the affine of bn(z) and the incoming gradient is that of the BatchNorm
@@ -731,17 +754,23 @@ class ConvBnReluFn(torch.autograd.Function):
         ctx.bias_ref = weakref.ref(bias) if bias is not None else None
         ctx.relu, ctx.dilation = bool(relu), int(dilation)
         ctx.head = head if (head is not None and relu and FUSE_HEAD_DZ) else None
+        ctx.link = link if (link is not None and relu and training and FUSE_AMSFN_BWD) else None
+        if ctx.link is not None:
+            link.gamma, link.beta, link.g = gamma.detach(), beta.detach(), None
         ctx.mark_non_differentiable(ss)
         return z, ss
 
     @staticmethod
     def backward(ctx, da, _dss):
         if da is None:
-            return (None,) * 17
+            return (None,) * 18
         x, x_ss, x2, x2_ss, z, weight, gamma, beta, ss = ctx.saved_tensors
         head = ctx.head if (ctx.head is not None and ctx.head.dy is not None) else None
         if head is not None and (da.data_ptr() != head.ptr or da._version != head.version):
             raise RuntimeError("the output of a head-fused conv+BN+ReLU layer had a consumer besides its 1x1 conv")
+        link = ctx.link if (ctx.link is not None and ctx.link.g is not None) else None
+        if link is not None and (da.data_ptr() != link.ptr or da._version != link.version):
+            raise RuntimeError("the output of an AMSFN branch layer had a consumer besides the fusion node")
         mr = ss[2:]
         B, Ca, H, W = x.shape
         Cout, Cin = weight.shape[0], weight.shape[1]
@@ -752,6 +781,8 @@ class ConvBnReluFn(torch.autograd.Function):
         relu, dil = ctx.relu, ctx.dilation
         if head is not None:
             sums = head.sums
+        elif link is not None:
+            sums = link.sums
         else:
             sums = take_bn_sums(da, z) if relu else None       # (the fused sums carry the ReLU mask)
             da = to_act(da, x.dtype)
@@ -785,6 +816,12 @@ class ConvBnReluFn(torch.autograd.Function):
                      Cout, mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(), dz.data_ptr(),
                      rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
             head.dy = head.w = head.sums = None
+        elif link is not None:
+            with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
+                call("mis_bn_relu_bwd_dz_scaled", z.data_ptr(), link.g.data_ptr(), link.scale_ptr, link.shift_ptr, link.ld,
+                     H * W, _dt(x), n_pix, Cout, mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(),
+                     dz.data_ptr(), rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
+            link.g = link.sums = link.keep = None
         else:
             with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
                 call("mis_bn_relu_bwd_dz" if relu else "mis_bn_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout,
@@ -813,7 +850,7 @@ class ConvBnReluFn(torch.autograd.Function):
         elif want_dw:
             dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=dil, defer=can_defer_wgrad(weight))
         data_gradient()
-        return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 class MaterializeFn(torch.autograd.Function):
@@ -1030,11 +1067,13 @@ class UpsampleFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # AMSFN pieces (model/utils/modules.py:791-871)
 # ---------------------------------------------------------------------------
-def conv_bn_relu_w(x, x_ss, weight, bias, bn, training):
-    """Like `conv_bn_relu` with an explicit [Cout, Cin, 3, 3] weight / bias (any autograd tensors)."""
+def conv_bn_relu_w(x, x_ss, weight, bias, bn, training, link=None):
+    """Like `conv_bn_relu` with an explicit [Cout, Cin, 3, 3] weight / bias (any autograd tensors).
+    link: a BranchGradLink shared with the AmsfnFuseFn that is the only consumer of (z, ss)."""
     momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
     return ConvBnReluFn.apply(x, x_ss, None, None, weight, bias, bn.weight, bn.bias, bn.running_mean,
-                              bn.running_var, bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum))
+                              bn.running_var, bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum),
+                              True, 1, None, link)
 
 
 def pointwise_as_3x3(weight):
@@ -1182,10 +1221,12 @@ def fan_out(x, x_ss, n, bn_sums=True):
 
 class AmsfnFuseFn(torch.autograd.Function):
     """Global average pools of the four branch outputs -> squeeze MLP -> sigmoid -> weighted sum
-    (modules.py:846-868) in one autograd node: three launches forward, five backward."""
+    (modules.py:846-868) in one autograd node: three launches forward, five backward.
+    links: four BranchGradLink objects shared with the layers that produced the branches (each branch read by
+    this node only): the backward then writes no branch gradients (see BranchGradLink)."""
 
     @staticmethod
-    def forward(ctx, z1, s1, z2, s2, z3, s3, z4, s4, W1, b1, W2, b2):
+    def forward(ctx, z1, s1, z2, s2, z3, s3, z4, s4, W1, b1, W2, b2, links=None):
         zs, sss = [z1, z2, z3, z4], [s1, s2, s3, s4]
         for t in zs:
             _check_act(t)
@@ -1207,6 +1248,7 @@ class AmsfnFuseFn(torch.autograd.Function):
                  s.data_ptr(), h.data_ptr(), w.data_ptr(), out.data_ptr(), ws.data_ptr(), _stream())
         ctx.save_for_backward(z1, s1, z2, s2, z3, s3, z4, s4, W1c, W2c, s, h, w)
         ctx.shapes = (W1.shape, W2.shape)
+        ctx.links = links
         return out
 
     @staticmethod
@@ -1216,19 +1258,35 @@ class AmsfnFuseFn(torch.autograd.Function):
         B, Cc, H, W = z1.shape
         dev = z1.device
         dout = to_act(dout, z1.dtype)
-        dact = [torch.empty_like(z1) for _ in range(4)]
         dW1 = torch.empty((Cc, 4 * Cc), dtype=torch.float32, device=dev)
         dW2 = torch.empty((4 * Cc, Cc), dtype=torch.float32, device=dev)
         db1 = torch.empty(Cc, dtype=torch.float32, device=dev)
         db2 = torch.empty(4 * Cc, dtype=torch.float32, device=dev)
+        s1s, s2s = ctx.shapes
+        links = ctx.links
+        if (FUSE_AMSFN_BWD and links is not None and len(links) == 4 and all(l is not None and l.gamma is not None for l in links)
+                and all(t is not None and t.dim() == 2 and t.shape[0] == 4 for t in sss) and B * H * W < 2 ** 31):
+            bn_sums = torch.empty((4, 2, Cc), dtype=torch.float32, device=dev)
+            shift = torch.empty((B, 4 * Cc), dtype=torch.float32, device=dev)
+            ws = workspace(query("mis_amsfn_lazy_workspace_bytes", B, H * W, Cc), dev)
+            with _prof("amsfn_fuse_bwd", 0, 5 * z1.numel() * z1.element_size()):
+                call("mis_amsfn_fuse_bwd_lazy", _ptr_array(zs), _ptr_array(sss), _ptr_array([l.gamma for l in links]),
+                     _ptr_array([l.beta for l in links]), dout.data_ptr(), _dt(z1), B, H * W, Cc, W1c.data_ptr(),
+                     W2c.data_ptr(), s.data_ptr(), h.data_ptr(), w.data_ptr(), bn_sums.data_ptr(), shift.data_ptr(),
+                     dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), ws.data_ptr(), _stream())
+            for k, l in enumerate(links):
+                l.g, l.sums, l.keep = dout, bn_sums[k], (w, shift)
+                l.scale_ptr, l.shift_ptr, l.ld = w.data_ptr() + 4 * k * Cc, shift.data_ptr() + 4 * k * Cc, 4 * Cc
+                l.ptr, l.version = dout.data_ptr(), dout._version
+            return (dout, None, dout, None, dout, None, dout, None, dW1.reshape(s1s), db1, dW2.reshape(s2s), db2, None)
+        dact = [torch.empty_like(z1) for _ in range(4)]
         ws = workspace(query("mis_amsfn_workspace_bytes", B, H * W, Cc), dev)
         with _prof("amsfn_fuse_bwd", 0, 10 * z1.numel() * z1.element_size()):
             call("mis_amsfn_fuse_bwd", _ptr_array(zs), _ptr_array(sss), dout.data_ptr(), _dt(z1), B, H * W, Cc,
                  W1c.data_ptr(), W2c.data_ptr(), s.data_ptr(), h.data_ptr(), w.data_ptr(), _ptr_array(dact),
                  dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), ws.data_ptr(), _stream())
-        s1s, s2s = ctx.shapes
         return (dact[0], None, dact[1], None, dact[2], None, dact[3], None, dW1.reshape(s1s), db1, dW2.reshape(s2s),
-                db2)
+                db2, None)
 
 
 class Conv1x1Fn(torch.autograd.Function):

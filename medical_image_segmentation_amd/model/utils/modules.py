@@ -103,10 +103,11 @@ class AMSFN(nn.Module):
                                         nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
         _init_like_reference(self)
 
-    def _dw_chain(self, seq, x, x_ss):
+    def _dw_chain(self, seq, x, x_ss, link=None):
         for i in range(0, len(seq), 3):
             W, b = F_.dwconv_as_3x3(seq[i].dconv, seq[i].pconv)
-            x, x_ss = F_.conv_bn_relu_w(x, x_ss, W, b, seq[i + 1], self.training)
+            x, x_ss = F_.conv_bn_relu_w(x, x_ss, W, b, seq[i + 1], self.training,
+                                        link if i + 3 >= len(seq) else None)
         return x, x_ss
 
     def forward_lazy(self, x, x_ss=None, input_read_elsewhere=False):
@@ -114,14 +115,16 @@ class AMSFN(nn.Module):
         their gradients are summed in one kernel (functional.fan_out), which also produces the BatchNorm-backward
         sums of the layer that wrote x unless the caller says that x has further readers."""
         x1, x2, x3, x4 = F_.fan_out(x, x_ss, 4, bn_sums=not input_read_elsewhere)
+        # each branch output is read by the fusion node alone: its gradient is never written (functional.BranchGradLink)
+        links = [F_.BranchGradLink() for _ in range(4)] if self.training else [None] * 4
         pooled = F_.MaxPool3x3Fn.apply(x1, x_ss)
         c1 = F_.conv_bn_relu_w(pooled, None, F_.pointwise_as_3x3(self.conv1x1[1].weight), self.conv1x1[1].bias,
-                               self.conv1x1[2], self.training)
-        c2 = self._dw_chain(self.cbr1, x2, x_ss)
-        c3 = self._dw_chain(self.cbr2, x3, x_ss)
-        c4 = self._dw_chain(self.cbr3, x4, x_ss)
+                               self.conv1x1[2], self.training, links[0])
+        c2 = self._dw_chain(self.cbr1, x2, x_ss, links[1])
+        c3 = self._dw_chain(self.cbr2, x3, x_ss, links[2])
+        c4 = self._dw_chain(self.cbr3, x4, x_ss, links[3])
         fused = F_.AmsfnFuseFn.apply(*c1, *c2, *c3, *c4, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
-                                     self.mlp[2].bias)
+                                     self.mlp[2].bias, links if self.training else None)
         return F_.conv_bn_relu_w(fused, None, F_.pointwise_as_3x3(self.final_conv[0].weight),
                                  self.final_conv[0].bias, self.final_conv[1], self.training)
 

@@ -102,6 +102,87 @@ def test_amsfn_block_golden(golden):
         assert rel_err(p.grad, ref) < 1e-3, k
 
 
+@pytest.mark.parametrize("Cout,Cin", [(8, 8), (6, 6), (3, 6), (5, 7), (16, 8), (33, 17), (1, 1)])
+def test_dwconv_composition_matches_autograd(Cout, Cin):
+    """DWConv = pointwise(depthwise(x)) as one dense 3x3 conv (modules.py:52-60): W[o][i] = P[o][i] * D[i],
+    b = bp + P bd, and the chain rule back to (P, D, bd, bp) — against the same expressions under torch autograd,
+    for channel counts whose product is not a multiple of the 8-lane groups of the backward kernel."""
+    from medical_image_segmentation_amd import functional as F_
+    g = torch.Generator().manual_seed(Cout * 100 + Cin)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    P0, D0, bd0, bp0 = mk(Cout, Cin, 1, 1), mk(Cin, 1, 3, 3), mk(Cin), mk(Cout)
+    gW, gb = mk(Cout, Cin, 3, 3), mk(Cout)
+    got = [t.clone().requires_grad_(True) for t in (P0, D0, bd0, bp0)]
+    W, b = F_.DwComposeFn.apply(*got)
+    torch.autograd.backward([W, b], [gW, gb])
+    ref = [t.clone().double().requires_grad_(True) for t in (P0, D0, bd0, bp0)]
+    Wr = ref[0].reshape(Cout, Cin, 1, 1) * ref[1].reshape(1, Cin, 3, 3)
+    br = ref[3] + ref[0].reshape(Cout, Cin) @ ref[2]
+    torch.autograd.backward([Wr, br], [gW.double(), gb.double()])
+    assert rel_err(W, Wr) < 1e-6 and rel_err(b, br) < 1e-6
+    for a, r, name in zip(got, ref, ("pconv.weight", "dconv.weight", "dconv.bias", "pconv.bias")):
+        assert rel_err(a.grad, r.grad) < 1e-5, name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,hw", [(8, (12, 20)), (16, (33, 17)), (6, (9, 10)), (32, (64, 64))])
+def test_amsfn_backward_without_branch_gradients(dtype, C, hw):
+    """The default backward keeps the four branch gradients out of memory (the branch layers rebuild them from the
+    fusion's output gradient and two small tables, their BatchNorm sums come from the pass that forms the
+    fusion-weight gradient); FUSE_AMSFN_BWD = False writes them and reduces them per layer.  float32: the two
+    forms agree to 2e-5 of each tensor's scale.  bfloat16: the written gradients are rounded to bfloat16, the
+    rebuilt ones are not, so the forms differ by that rounding (amplified where a gradient is a small variation
+    on a large per-sample constant, which BatchNorm's backward subtracts): each form is measured against the
+    float32 gradients instead."""
+    from medical_image_segmentation_amd import functional as F_
+    from medical_image_segmentation_amd.model.utils.modules import AMSFN
+    torch.manual_seed(C)
+    blk = AMSFN(C).to(DEV).train()
+    x0 = torch.randn(3, C, *hw, device=DEV).relu()
+    gy = torch.randn(3, C, *hw, device=DEV)
+
+    def run(dt, fused):
+        F_.FUSE_AMSFN_BWD = fused
+        blk.zero_grad()
+        x = x0.to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        z, ss = blk.forward_lazy(x)
+        y = F_.materialize(z, ss)
+        y.backward(gy.to(dt).contiguous(memory_format=torch.channels_last))
+        F_.FUSE_AMSFN_BWD = True
+        return y.detach().float(), x.grad.float(), {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    def close(got, ref, tol, what):
+        assert rel_err(got[1], ref[1]) < tol, f"{what}: input gradient"
+        typical = max(float(g.abs().max()) for g in ref[2].values())
+        for k, g in ref[2].items():
+            if k.endswith(("pconv.bias", "dconv.bias", "conv1x1.1.bias", "final_conv.0.bias")):
+                # analytically zero under train-mode BN: every form returns rounding noise of the large sums behind it
+                assert float(got[2][k].abs().max()) < (1e-6 if dtype == torch.float32 else 1e-2) * typical, (what, k)
+                continue
+            scale = max(float(g.abs().max()), 1e-2 * typical)
+            assert float((got[2][k] - g).abs().max()) < tol * scale, (what, k)
+
+    fused, written = run(dtype, True), run(dtype, False)
+    assert torch.equal(fused[0], written[0])
+    if dtype == torch.float32:
+        close(fused, written, 2e-5, "fused vs written")
+        return
+    # bfloat16: distance (relative L2 norm over the input gradient and all parameter gradients that are not
+    # analytically zero) of each form from the float32 gradients of the same block; ReLU masks of a bfloat16
+    # forward differ from the float32 ones, so the distances are per cents — the rebuilt form must not be the
+    # farther one by more than a quarter
+    ref = run(torch.float32, True)
+    skip = ("pconv.bias", "dconv.bias", "conv1x1.1.bias", "final_conv.0.bias")
+
+    def dist(got):
+        pairs = [(got[1], ref[1])] + [(got[2][k], g) for k, g in ref[2].items() if not k.endswith(skip)]
+        num = sum(float((a.double() - b.double()).pow(2).sum()) for a, b in pairs)
+        return (num / sum(float(b.double().pow(2).sum()) for _, b in pairs)) ** 0.5
+
+    d_fused, d_written = dist(fused), dist(written)
+    assert d_written < 0.2 and d_fused < max(1.25 * d_written, 1e-2), (d_fused, d_written)
+
+
 # measured: 1.5e-4 / 1.1e-3 (aunet_a), 4.5e-3 / 1.4e-2 (aunet_b: one ReLU of a large-gradient pixel flips, as in the U-Net goldens)
 A_UNET_GRAD_NORM_TOL, A_UNET_GRAD_NORM_REL_TOL = 1e-2, 3e-2
 
