@@ -246,35 +246,49 @@ __global__ __launch_bounds__(TPB) void mlp_fwd_kernel(const float* __restrict__ 
 }
 
 // Backward, per sample: g2 = dw * w * (1-w) [4C];  dh = W2^T g2;  g1 = dh * [h > 0] [C];
-// ds = W1^T g1 [4C].  g1 and g2 are kept for the parameter gradients.
-__global__ __launch_bounds__(TPB) void mlp_bwd_sample_kernel(const float* __restrict__ dw, const float* __restrict__ w,
-                                                             const float* __restrict__ h,
-                                                             const float* __restrict__ W1,
-                                                             const float* __restrict__ W2, int C,
-                                                             float* __restrict__ g1, float* __restrict__ g2,
-                                                             float* __restrict__ ds) {
-  extern __shared__ float sm[];              // g2 [4C] then g1 [C]
-  const int b = blockIdx.x, C4 = 4 * C;
+// ds = W1^T g1 [4C].  g1 and g2 are kept for the parameter gradients.  One workgroup of MLP_BWD_THREADS per
+// sample; the sum over the 4C rows of W2 is split over blockDim/C groups of C threads (each thread keeps its
+// column, so the loads stay coalesced) and the groups are added in a fixed order.
+constexpr int MLP_BWD_THREADS = 1024;
+__global__ __launch_bounds__(MLP_BWD_THREADS) void mlp_bwd_sample_kernel(const float* __restrict__ dw,
+                                                                         const float* __restrict__ w,
+                                                                         const float* __restrict__ h,
+                                                                         const float* __restrict__ W1,
+                                                                         const float* __restrict__ W2, int C,
+                                                                         float* __restrict__ g1, float* __restrict__ g2,
+                                                                         float* __restrict__ ds) {
+  extern __shared__ float sm[];              // g2 [4C] | g1 [C] | partial sums [blockDim/C][C]
+  const int b = blockIdx.x, C4 = 4 * C, nt = blockDim.x;
   float* s2 = sm;
   float* s1 = sm + C4;
-  for (int o = threadIdx.x; o < C4; o += TPB) {
+  float* part = s1 + C;
+  for (int o = threadIdx.x; o < C4; o += nt) {
     const float y = w[(int64_t)b * C4 + o];
     const float g = dw[(int64_t)b * C4 + o] * y * (1.0f - y);
     s2[o] = g;
     g2[(int64_t)b * C4 + o] = g;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += TPB) {
+  const int groups = nt / C, i = threadIdx.x % C, grp = threadIdx.x / C;
+  if (grp < groups) {
     float acc = 0.f;
-    for (int o = 0; o < C4; o++) acc += W2[(int64_t)o * C + i] * s2[o];
-    acc = (h[(int64_t)b * C + i] > 0.f) ? acc : 0.f;
-    s1[i] = acc;
-    g1[(int64_t)b * C + i] = acc;
+#pragma unroll 8
+    for (int o = grp; o < C4; o += groups) acc += W2[(int64_t)o * C + i] * s2[o];
+    part[grp * C + i] = acc;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < C4; j += TPB) {
+  if (threadIdx.x < C) {
     float acc = 0.f;
-    for (int i = 0; i < C; i++) acc += W1[(int64_t)i * C4 + j] * s1[i];
+    for (int q = 0; q < groups; q++) acc += part[q * C + threadIdx.x];
+    acc = (h[(int64_t)b * C + threadIdx.x] > 0.f) ? acc : 0.f;
+    s1[threadIdx.x] = acc;
+    g1[(int64_t)b * C + threadIdx.x] = acc;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < C4; j += nt) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < C; q++) acc += W1[(int64_t)q * C4 + j] * s1[q];
     ds[(int64_t)b * C4 + j] = acc;
   }
 }
@@ -662,7 +676,7 @@ int fuse_bwd_t(const Branches& br, const Grads& gr, const void* dout, int B, int
   MIS_CHECK_LAUNCH("branch_dot_kernel");
   launch_reduce_partials(partials, rows, B * C4, dw, st);
   MIS_CHECK_LAUNCH("reduce_partials_kernel");
-  mlp_bwd_sample_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(dw, w, h, W1, W2, C, g1, g2, ds);
+  mlp_bwd_sample_kernel<<<B, MLP_BWD_THREADS, (size_t)(5 * C + MLP_BWD_THREADS) * sizeof(float), st>>>(dw, w, h, W1, W2, C, g1, g2, ds);
   MIS_CHECK_LAUNCH("mlp_bwd_sample_kernel");
   const int64_t n = (int64_t)B * HW * C;
   if (V == VecOf<T>::N)
@@ -699,7 +713,7 @@ int fuse_bwd_lazy_t(const Branches& br, const BranchBn& bn, const void* dout, in
   MIS_CHECK_LAUNCH("branch_stats_kernel");
   launch_reduce_partials(partials, rows, ST_N * B * C4, stats, st);
   MIS_CHECK_LAUNCH("reduce_partials_kernel");
-  mlp_bwd_sample_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(stats, w, h, W1, W2, C, g1, g2, ds);
+  mlp_bwd_sample_kernel<<<B, MLP_BWD_THREADS, (size_t)(5 * C + MLP_BWD_THREADS) * sizeof(float), st>>>(stats, w, h, W1, W2, C, g1, g2, ds);
   MIS_CHECK_LAUNCH("mlp_bwd_sample_kernel");
   branch_bn_sums_kernel<<<cdiv(C4, TPB), TPB, 0, st>>>(stats, w, ds, 1.0f / (float)HW, B, C, bn_sums, shift);
   MIS_CHECK_LAUNCH("branch_bn_sums_kernel");

@@ -252,6 +252,21 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
   // index advances by a constant: no division in the loop
   int64_t pix = i0 / CV;
   const int64_t pix_step = ((int64_t)gridDim.x * EW_THREADS) / CV;
+  // SCALED: the tables' rows of the current sample stay in registers; the pixel index inside the sample is
+  // tracked by additions (no division in the loop), and the rows are reloaded when it wraps
+  float gsc[SCALED ? V : 1], gsh[SCALED ? V : 1];
+  unsigned s_rem = 0, s_row = 0;
+  const unsigned n_samples = SCALED ? (unsigned)((n_vec / CV) / px_per_sample) : 0;
+  if constexpr (SCALED) {
+    s_row = (unsigned)pix / px_per_sample;
+    s_rem = (unsigned)pix - s_row * px_per_sample;
+    const int64_t row = (int64_t)(s_row < n_samples ? s_row : 0) * coef_ld + c0;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      gsc[k] = head_w[row + k];
+      gsh[k] = g_shift[row + k];
+    }
+  }
   for (int64_t i = i0; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS, pix += pix_step) {
     float zv[V], gv[V], o[V];
     vload<T, V>(z + i * V, zv);
@@ -280,10 +295,23 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
     } else {
       vload<T, V>(da + i * V, gv);
       if constexpr (SCALED) {
-        // (32-bit: the host checks the pixel count; a thread keeps its channel vector, so only the sample moves)
-        const int64_t row = (int64_t)((unsigned)pix / px_per_sample) * coef_ld + c0;
 #pragma unroll
-        for (int k = 0; k < V; k++) gv[k] = gv[k] * head_w[row + k] + g_shift[row + k];
+        for (int k = 0; k < V; k++) gv[k] = gv[k] * gsc[k] + gsh[k];
+        s_rem += (unsigned)pix_step;                 // (32-bit: the host checks the pixel count)
+        if (s_rem >= px_per_sample) {
+          do {
+            s_rem -= px_per_sample;
+            ++s_row;
+          } while (s_rem >= px_per_sample);
+          if (s_row < n_samples) {
+            const int64_t row = (int64_t)s_row * coef_ld + c0;
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+              gsc[k] = head_w[row + k];
+              gsh[k] = g_shift[row + k];
+            }
+          }
+        }
       }
     }
 #pragma unroll

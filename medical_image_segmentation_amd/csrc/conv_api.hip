@@ -86,7 +86,7 @@ int mis_pack_conv3x3_weights_multi(const mis_pack_job* jobs, int n_jobs, int tot
 int mis_conv3x3_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout) {
   if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
   return use_mfma(dtype, Cin, Cout) ? conv3x3_mfma_stats_rows(dtype, B, H, W, Cin, Cout)
-                                    : conv3x3_direct_stats_rows((int64_t)B * H * W, B, H, W, Cin);
+                                    : conv3x3_direct_stats_rows((int64_t)B * H * W, B, H, W, Cin, Cout);
 }
 
 size_t mis_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {

@@ -404,6 +404,258 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------
+// Narrow layers: ONE output channel, or ONE input channel with a wide output.  DoubleConv(base, n_classes) has
+// n_classes / 4 middle channels (model/utils/modules.py:13-14) — one for the 4-class output block of A_UNet
+// (model/a_unet.py:52) — so its first conv is 32 -> 1 at full resolution, and the data gradient of that conv
+// is 1 -> 32.  Thread = (pixel column, 16-byte channel vector cv of the wide side): the CV lanes of a pixel
+// read / write one contiguous pixel, the weights of a lane's channels (9 taps x V) stay in registers, and a
+// lane walks NR consecutive rows of its column so that an input row it has loaded (and converted, for a lazy
+// input) serves three output rows.  HBM-bound on the wide tensor.
+// ---------------------------------------------------------------------------------
+constexpr int NR = 8;                    // rows per thread and item
+
+template <int CV>
+__device__ __forceinline__ float sum_cv(float a) {      // total over the CV adjacent lanes of a pixel, on every one
+  if constexpr (CV >= 2) a += dpp_move<0xB1>(a);
+  if constexpr (CV >= 4) a += dpp_move<0x4E>(a);
+  if constexpr (CV >= 8) a += dpp_move<0x141>(a);
+  return a;
+}
+
+// z[p] = bias + sum_{tap, ci} act(x)[p + off(tap)][ci] * w[tap][ci]      (Cin = CV*V -> 1 channel)
+template <typename T, int V, int CV>
+__global__ __launch_bounds__(CD_THREADS) void conv3x3_to1_kernel(const T* __restrict__ x,
+                                                                 const T* __restrict__ wp /*[9][1][Cin]*/,
+                                                                 const float* __restrict__ bias, T* __restrict__ z,
+                                                                 float* __restrict__ partials /*[gridDim.x][2] or null*/,
+                                                                 int B, int H, int W,
+                                                                 const float* __restrict__ in_aff /*[2][Cin] or null*/) {
+  constexpr int Cin = CV * V, PXB = CD_THREADS / CV;
+  __shared__ float red[2 * (CD_THREADS / 64)];
+  const int tid = threadIdx.x, cv = tid % CV, px = tid / CV, c0 = cv * V;
+  float wr[9][V], asc[V], ash[V];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int k = 0; k < V; k++) wr[t][k] = to_f32(wp[t * Cin + c0 + k]);
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    asc[k] = in_aff ? in_aff[c0 + k] : 1.f;
+    ash[k] = in_aff ? in_aff[Cin + c0 + k] : 0.f;
+  }
+  const float b0 = bias ? bias[0] : 0.f;
+  const int strips = (H + NR - 1) / NR, xblocks = (W + PXB - 1) / PXB, items = B * strips * xblocks;
+  float st[2] = {0.f, 0.f};
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int xb = item % xblocks, sy = (item / xblocks) % strips, b = item / (xblocks * strips);
+    const int gx = xb * PXB + px, y0 = sy * NR;
+    float acc[NR];
+#pragma unroll
+    for (int o = 0; o < NR; o++) acc[o] = 0.f;
+#pragma unroll
+    for (int ri = 0; ri < NR + 2; ri++) {
+      const int yy = y0 - 1 + ri;
+      if (yy < 0 || yy >= H) continue;                 // (uniform over the workgroup)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const int xx = gx + dx;
+        float av[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) av[k] = 0.f;
+        if (xx >= 0 && xx < W) {
+          vload<T, V>(x + ((int64_t)(b * H + yy) * W + xx) * Cin + c0, av);
+          if (in_aff) {
+#pragma unroll
+            for (int k = 0; k < V; k++) av[k] = to_f32(from_f32<T>(fmaxf(av[k] * asc[k] + ash[k], 0.f)));
+          }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+          const int o = ri - ky;                       // output row that sees this input row through tap row ky
+          if (o < 0 || o >= NR) continue;
+#pragma unroll
+          for (int k = 0; k < V; k++) acc[o] += av[k] * wr[ky * 3 + dx + 1][k];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < NR; o++) {
+      const float t = sum_cv<CV>(acc[o]) + b0;
+      const int gy = y0 + o;
+      if (cv == 0 && gy < H && gx < W) {
+        z[(int64_t)(b * H + gy) * W + gx] = from_f32<T>(t);
+        st[0] += t;
+        st[1] += t * t;
+      }
+    }
+  }
+  if (partials) {
+    block_sum<2>(st, red);
+    if (tid < 2) partials[(int64_t)blockIdx.x * 2 + tid] = tid == 0 ? st[0] : st[1];
+  }
+}
+
+// z[p][co] = bias[co] + sum_tap act(x)[p + off(tap)] * w[tap][co]        (1 channel -> Cout = CV*V)
+// The column's 3x3 window slides down the strip: three new scalars per output row.
+template <typename T, int V, int CV, bool STATS>
+__global__ __launch_bounds__(CD_THREADS, STATS ? 1 : 3) void conv3x3_from1_kernel(const T* __restrict__ x,
+                                                                      const T* __restrict__ wp /*[9][Cout][1]*/,
+                                                                      const float* __restrict__ bias, T* __restrict__ z,
+                                                                      float* __restrict__ partials /*[gridDim.x][2][Cout]*/,
+                                                                      int B, int H, int W,
+                                                                      const float* __restrict__ in_aff /*[2][1] or null*/) {
+  constexpr int Cout = CV * V, PXB = CD_THREADS / CV;
+  __shared__ float red[STATS ? CD_THREADS : 1][2 * V];
+  const int tid = threadIdx.x, cv = tid % CV, px = tid / CV, c0 = cv * V;
+  float wr[9][V], bv[V], st[2][STATS ? V : 1];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int k = 0; k < V; k++) wr[t][k] = to_f32(wp[t * Cout + c0 + k]);
+#pragma unroll
+  for (int k = 0; k < V; k++) bv[k] = bias ? bias[c0 + k] : 0.f;
+  if constexpr (STATS) {
+#pragma unroll
+    for (int k = 0; k < V; k++) st[0][k] = st[1][k] = 0.f;
+  }
+  const float asc = in_aff ? in_aff[0] : 1.f, ash = in_aff ? in_aff[1] : 0.f;
+  const int strips = (H + NR - 1) / NR, xblocks = (W + PXB - 1) / PXB, items = B * strips * xblocks;
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int xb = item % xblocks, sy = (item / xblocks) % strips, b = item / (xblocks * strips);
+    const int gx = xb * PXB + px, y0 = sy * NR;
+    auto row = [&](int yy, float (&r)[3]) {            // window row yy (padding = 0)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const int xx = gx + dx;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          v = to_f32(x[(int64_t)(b * H + yy) * W + xx]);
+          if (in_aff) v = to_f32(from_f32<T>(fmaxf(v * asc + ash, 0.f)));
+        }
+        r[dx + 1] = v;
+      }
+    };
+    float xr[3][3];
+    row(y0 - 1, xr[0]);
+    row(y0, xr[1]);
+#pragma unroll
+    for (int o = 0; o < NR; o++) {
+      const int gy = y0 + o;
+      if (gy >= H) continue;                           // (uniform over the workgroup)
+      row(gy + 1, xr[(o + 2) % 3]);
+      float acc[V];
+#pragma unroll
+      for (int k = 0; k < V; k++) acc[k] = bv[k];
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const float v = xr[(o + t / 3) % 3][t % 3];
+#pragma unroll
+        for (int k = 0; k < V; k++) acc[k] += v * wr[t][k];
+      }
+      if (gx < W) {
+        vstore<T, V>(z + ((int64_t)(b * H + gy) * W + gx) * Cout + c0, acc);
+        if constexpr (STATS) {
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            st[0][k] += acc[k];
+            st[1][k] += acc[k] * acc[k];
+          }
+        }
+      }
+    }
+  }
+  if constexpr (STATS) {
+    // fixed-order sum over the pixel lanes of each channel vector
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int k = 0; k < V; k++) red[tid][q * V + k] = st[q][k];
+    __syncthreads();
+    for (int j = tid; j < 2 * Cout; j += CD_THREADS) {
+      const int q = j / Cout, c = j % Cout, cvj = c / V, k = c % V;
+      float a = 0.f;
+      for (int t = cvj; t < CD_THREADS; t += CV) a += red[t][q * V + k];
+      partials[((int64_t)blockIdx.x * 2 + q) * Cout + c] = a;
+    }
+  }
+}
+
+// dW[0][ci][tap] = sum_p dz[p] * act(x)[p + off(tap)][ci]               (Cin = CV*V, one output channel)
+// A lane walks the INPUT pixels of its column: each is loaded (and converted) once and multiplied by the 9
+// gradients around it; partials [gridDim.x][Cin][9] (the layout of the generic direct kernel for Cout = 1).
+template <typename T, int V, int CV>
+__global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_to1_kernel(const T* __restrict__ x, const T* __restrict__ dz,
+                                                                       float* __restrict__ partials, int B, int H,
+                                                                       int W, const float* __restrict__ x_aff) {
+  constexpr int Cin = CV * V, PXB = CD_THREADS / CV, NW = CD_THREADS / 64;
+  __shared__ float red[NW][CV][9 * V];
+  const int tid = threadIdx.x, cv = tid % CV, px = tid / CV, c0 = cv * V;
+  float asc[V], ash[V], acc[9][V];
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    asc[k] = x_aff ? x_aff[c0 + k] : 1.f;
+    ash[k] = x_aff ? x_aff[Cin + c0 + k] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int k = 0; k < V; k++) acc[t][k] = 0.f;
+  const int strips = (H + NR - 1) / NR, xblocks = (W + PXB - 1) / PXB, items = B * strips * xblocks;
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int xb = item % xblocks, sy = (item / xblocks) % strips, b = item / (xblocks * strips);
+    const int gx = xb * PXB + px, y0 = sy * NR;
+    if (gx >= W) continue;                             // (no cross-lane work inside the loop)
+    float g[NR + 2][3];                                // gradients around the column (0 outside the image)
+#pragma unroll
+    for (int ri = 0; ri < NR + 2; ri++) {
+      const int yy = y0 - 1 + ri;
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const int xx = gx + dx;
+        g[ri][dx + 1] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? to_f32(dz[(int64_t)(b * H + yy) * W + xx]) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      const int qy = y0 + i;
+      if (qy >= H) continue;
+      float av[V];
+      vload<T, V>(x + ((int64_t)(b * H + qy) * W + gx) * Cin + c0, av);
+      if (x_aff) {
+#pragma unroll
+        for (int k = 0; k < V; k++) av[k] = to_f32(from_f32<T>(fmaxf(av[k] * asc[k] + ash[k], 0.f)));
+      }
+      // tap (ky, kx) pairs this input pixel with the output pixel (qy - ky + 1, gx - kx + 1)
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const float gv = g[i + 2 - t / 3][2 - t % 3];
+#pragma unroll
+        for (int k = 0; k < V; k++) acc[t][k] += gv * av[k];
+      }
+    }
+  }
+  // lanes with the same channel vector: xor butterflies over the pixel bits of the lane index, then the waves
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      float v = acc[t][k];
+#pragma unroll
+      for (int m = CV; m < 64; m <<= 1) v += __shfl_xor(v, m);
+      if (lane < CV) red[wv][lane][t * V + k] = v;
+    }
+  __syncthreads();
+  for (int j = tid; j < CV * 9 * V; j += CD_THREADS) {
+    const int cvj = j / (9 * V), e = j % (9 * V), t = e / V, k = e % V;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) a += red[w][cvj][e];
+    partials[(int64_t)blockIdx.x * 9 * Cin + (cvj * V + k) * 9 + t] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // 1x1 output convolution
 // ---------------------------------------------------------------------------------
 template <typename T, int V, int CO>
@@ -702,8 +954,11 @@ static int first_layer_grid(int B, int H, int W) {
   return cdiv(n_tiles, per);
 }
 
-int conv3x3_direct_stats_rows(int64_t n_pix, int B, int H, int W, int Cin) {
-  if (Cin == 1 || Cin == 3) return first_layer_grid(B, H, W);
+// Workgroups (= rows of statistics partials) of the forward kernels; every kernel walks its work with a grid
+// stride, so the count depends on the shape alone (not on which kernel the pointers' alignment allows).
+int conv3x3_direct_stats_rows(int64_t n_pix, int B, int H, int W, int Cin, int Cout) {
+  // one input channel into whole channel vectors: the strip kernel wants many short workgroups
+  if ((Cin == 1 || Cin == 3) && !(Cin == 1 && Cout >= 16 && Cout % 4 == 0)) return first_layer_grid(B, H, W);
   int gx = cdiv(n_pix, CD_THREADS);
   return gx > CD_MAX_BLOCKS ? CD_MAX_BLOCKS : gx;
 }
@@ -715,9 +970,53 @@ int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const
   if (gx > CD_MAX_BLOCKS) gx = CD_MAX_BLOCKS;
   dim3 grid(gx, cdiv(Cout, CO_T));
   float* partials = stats ? (float*)workspace : nullptr;
-  if (Cin == 1 || Cin == 3) {
+  const int NV = dtype == MIS_F32 ? 4 : 8;             // channels per 16-byte vector
+  const bool small32 = n_pix < ((int64_t)1 << 31) / 64;      // (the narrow kernels index pixels in 32 bits)
+  // narrow layers: wide side in whole vectors, 1 / 2 / 4 / 8 of them (or one 8-byte bf16 vector of 4 channels)
+  auto vecs = [&](int C, const void* p) {
+    if (((uintptr_t)p % 16) != 0 || C % NV != 0) return 0;
+    const int cv = C / NV;
+    return (cv == 1 || cv == 2 || cv == 4 || cv == 8) ? cv : 0;
+  };
+#define NARROW_CV(KERNEL, TT, VV, ...)                                                      \
+  switch (cv) {                                                                             \
+    case 1: KERNEL<TT, VV, 1><<<grid.x, CD_THREADS, 0, st>>>(__VA_ARGS__); break;           \
+    case 2: KERNEL<TT, VV, 2><<<grid.x, CD_THREADS, 0, st>>>(__VA_ARGS__); break;           \
+    case 4: KERNEL<TT, VV, 4><<<grid.x, CD_THREADS, 0, st>>>(__VA_ARGS__); break;           \
+    default: KERNEL<TT, VV, 8><<<grid.x, CD_THREADS, 0, st>>>(__VA_ARGS__); break;          \
+  }
+  if (Cin == 1 && small32 && vecs(Cout, z)) {
+    const int cv = vecs(Cout, z);
+    grid.x = conv3x3_direct_stats_rows(n_pix, B, H, W, Cin, Cout);
+#define FROM1(TT, VV, CVV)                                                                                              \
+  if (partials)                                                                                                         \
+    conv3x3_from1_kernel<TT, VV, CVV, true><<<grid.x, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)wp, bias, (TT*)z,   \
+                                                                             partials, B, H, W, in_aff);               \
+  else                                                                                                                  \
+    conv3x3_from1_kernel<TT, VV, CVV, false><<<grid.x, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)wp, bias, (TT*)z,  \
+                                                                              partials, B, H, W, in_aff);
+#define FROM1_CV(TT, VV)                                                                                                \
+  switch (cv) {                                                                                                         \
+    case 1: FROM1(TT, VV, 1) break;                                                                                     \
+    case 2: FROM1(TT, VV, 2) break;                                                                                     \
+    case 4: FROM1(TT, VV, 4) break;                                                                                     \
+    default: FROM1(TT, VV, 8) break;                                                                                    \
+  }
+    if (dtype == MIS_F32) FROM1_CV(float, 4) else FROM1_CV(bf16, 8)
+#undef FROM1_CV
+#undef FROM1
+  } else if (Cout == 1 && small32 && (vecs(Cin, x) || (dtype == MIS_BF16 && Cin == 4 && ((uintptr_t)x % 8) == 0))) {
+    const int cv = vecs(Cin, x);
+    if (dtype == MIS_F32)
+      NARROW_CV(conv3x3_to1_kernel, float, 4, (const float*)x, (const float*)wp, bias, (float*)z, partials, B, H, W, in_aff)
+    else if (cv)
+      NARROW_CV(conv3x3_to1_kernel, bf16, 8, (const bf16*)x, (const bf16*)wp, bias, (bf16*)z, partials, B, H, W, in_aff)
+    else
+      conv3x3_to1_kernel<bf16, 4, 1><<<grid.x, CD_THREADS, 0, st>>>((const bf16*)x, (const bf16*)wp, bias, (bf16*)z,
+                                                                     partials, B, H, W, in_aff);
+  } else if (Cin == 1 || Cin == 3) {
     const int ftx = cdiv(W, F_TW), fty = cdiv(H, F_TH);
-    grid.x = first_layer_grid(B, H, W);
+    grid.x = conv3x3_direct_stats_rows(n_pix, B, H, W, Cin, Cout);
 #define FIRST_LAUNCH(TT, CIN)                                                                               \
   conv3x3_first_kernel<TT, CIN><<<grid, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)wp, bias, (TT*)z, partials, B, \
                                                              H, W, Cout, in_aff, ftx, fty, B * ftx * fty)
@@ -749,6 +1048,7 @@ int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const
 #undef DIRECT_COT
 #undef DIRECT_LAUNCH
   }
+#undef NARROW_CV
   MIS_CHECK_LAUNCH("conv3x3_direct_kernel");
   if (stats && (void*)stats != workspace) {      // stats == workspace: the caller reduces the partial rows itself
     launch_reduce_partials(partials, grid.x, 2 * Cout, stats, st);
@@ -788,8 +1088,12 @@ int wgrad_direct_blocks(int64_t n_pix, int Cin, int Cout) {
 }
 }  // namespace
 
+constexpr int TO1_WGRAD_BLOCKS = 512;    // workgroups (= partial rows) of the one-output-channel weight gradient
+
 size_t conv3x3_direct_wgrad_workspace_bytes(int64_t n_pix, int Cin, int Cout) {
-  return align256((size_t)wgrad_direct_blocks(n_pix, Cin, Cout) * 9 * Cin * Cout * sizeof(float));
+  const int rows = Cout == 1 && wgrad_direct_blocks(n_pix, Cin, Cout) < TO1_WGRAD_BLOCKS ? TO1_WGRAD_BLOCKS
+                                                                                         : wgrad_direct_blocks(n_pix, Cin, Cout);
+  return align256((size_t)rows * 9 * Cin * Cout * sizeof(float));
 }
 
 int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int dtype, int B, int H, int W, int Cin,
@@ -799,9 +1103,28 @@ int conv3x3_direct_wgrad(const void* x, const float* x_aff, const void* dz, int 
     mis_set_error("conv3x3_wgrad: needs a workspace and B*H*W < 2^31");
     return MIS_ERR_ARG;
   }
+  float* partials = (float*)workspace;
+  const int NV = dtype == MIS_F32 ? 4 : 8;
+  const int cv = (Cin % NV == 0 && ((uintptr_t)x % 16) == 0) ? Cin / NV : 0;
+  if (Cout == 1 && n_pix < ((int64_t)1 << 31) / 64 && (cv == 1 || cv == 2 || cv == 4 || cv == 8)) {
+    const int items = B * cdiv(H, NR) * cdiv(W, CD_THREADS / cv);
+    const int nb = items < TO1_WGRAD_BLOCKS ? items : TO1_WGRAD_BLOCKS;
+#define TO1_WGRAD(TT, VV)                                                                                          \
+  switch (cv) {                                                                                                    \
+    case 1: conv3x3_wgrad_to1_kernel<TT, VV, 1><<<nb, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)dz, partials, B, H, W, x_aff); break; \
+    case 2: conv3x3_wgrad_to1_kernel<TT, VV, 2><<<nb, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)dz, partials, B, H, W, x_aff); break; \
+    case 4: conv3x3_wgrad_to1_kernel<TT, VV, 4><<<nb, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)dz, partials, B, H, W, x_aff); break; \
+    default: conv3x3_wgrad_to1_kernel<TT, VV, 8><<<nb, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)dz, partials, B, H, W, x_aff); break; \
+  }
+    if (dtype == MIS_F32) TO1_WGRAD(float, 4) else TO1_WGRAD(bf16, 8)
+#undef TO1_WGRAD
+    MIS_CHECK_LAUNCH("conv3x3_wgrad_to1_kernel");
+    launch_reduce_partials(partials, nb, 9 * Cin, dw, st);
+    MIS_CHECK_LAUNCH("reduce_partials_kernel");
+    return MIS_OK;
+  }
   const int nblk = wgrad_direct_blocks(n_pix, Cin, Cout);
   const int ftx = cdiv(W, F_TW), fty = cdiv(H, F_TH), n_tiles = B * ftx * fty;
-  float* partials = (float*)workspace;
   dim3 grid(nblk, cdiv(Cout, CO_T), Cin);
   if (dtype == MIS_F32)
     conv3x3_wgrad_direct_kernel<float><<<grid, CD_THREADS, 0, st>>>((const float*)x, (const float*)dz, partials, B, H,

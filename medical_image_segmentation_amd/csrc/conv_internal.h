@@ -5,7 +5,7 @@
 size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout);
 // Rows of per-workgroup partial statistics [rows][2][Cout] a forward launch leaves at the start
 // of the workspace (reduced into `stats` unless stats == workspace).
-int conv3x3_direct_stats_rows(int64_t n_pix, int B, int H, int W, int Cin);
+int conv3x3_direct_stats_rows(int64_t n_pix, int B, int H, int W, int Cin, int Cout);
 int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout, int dil = 1);
 // `in_aff` / `x_aff`: optional [2][Cin] (scale, shift) of a lazily stored input activation:
 // the kernel reads relu(x*scale + shift) instead of x (padding stays zero).

@@ -367,7 +367,11 @@ CBR_SHAPES = [(2, 1, 8, 16, 16), (2, 3, 8, 16, 16), (2, 8, 32, 16, 16), (1, 32, 
               # workgroup, two channel slices, a channel count without 16-byte stores
               (1, 1, 8, 37, 70), (2, 3, 12, 19, 130), (1, 1, 16, 100, 64), (3, 1, 8, 48, 200),
               # narrow outputs: 1, 2, 3 (padded to 4) and 4 channels per thread of the direct kernel
-              (2, 32, 1, 16, 16), (1, 16, 2, 24, 40), (2, 32, 3, 16, 24), (1, 8, 4, 19, 33), (2, 5, 1, 9, 11)]
+              (2, 32, 1, 16, 16), (1, 16, 2, 24, 40), (2, 32, 3, 16, 24), (1, 8, 4, 19, 33), (2, 5, 1, 9, 11),
+              # one output channel from 1 / 2 / 4 / 8 channel vectors (and the 8-byte bf16 vector), one input
+              # channel into as many: row strips of 8, ragged widths, images smaller than a strip
+              (2, 8, 1, 9, 13), (1, 16, 1, 20, 70), (1, 64, 1, 17, 33), (2, 4, 1, 12, 12), (3, 32, 1, 5, 130),
+              (1, 1, 32, 21, 35), (1, 1, 64, 9, 9), (2, 1, 4, 8, 8)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
