@@ -328,26 +328,43 @@ __global__ __launch_bounds__(TPB) void mlp_bwd_param_kernel(const float* __restr
 }
 
 // out[b][p][c] = sum_k act_k[b][p][c] * w[b][k*C + c]
+// Workgroup = (sample b, pixel chunk r); thread = (channel vector, pixel lane): the sample's four weight
+// vectors and the branches' affines stay in registers, the loop holds four tensor loads and one store.
 template <typename T, int V>
 __global__ __launch_bounds__(TPB) void wsum_fwd_kernel(Branches br, const float* __restrict__ w, int B, int HW, int C,
-                                                       T* __restrict__ out) {
-  const int CV = C / V;
-  const int64_t total = (int64_t)B * HW * CV;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
-    const int cv = (int)(i % CV);
-    const int b = (int)(i / ((int64_t)HW * CV));
+                                                       int rows, int chunk, T* __restrict__ out) {
+  const int CV = C / V, PL = TPB / CV;
+  const int r = blockIdx.x % rows, b = blockIdx.x / rows;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, c0 = cv * V;
+  if (pl >= PL) return;
+  float wk[4][V], sc[4][V], sh[4][V];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      wk[k][j] = w[(int64_t)b * 4 * C + k * C + c0 + j];
+      sc[k][j] = br.aff[k] ? br.aff[k][c0 + j] : 1.f;
+      sh[k][j] = br.aff[k] ? br.aff[k][C + c0 + j] : 0.f;
+    }
+  const int p1 = (r + 1) * chunk < HW ? (r + 1) * chunk : HW;
+#pragma unroll 2
+  for (int p = r * chunk + pl; p < p1; p += PL) {
+    const int64_t idx = ((int64_t)b * HW + p) * C + c0;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; j++) acc[j] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       float a[V];
-      act_vec<T, V>(br, k, C, i * V, cv * V, a);
-      const float* wk = w + (int64_t)b * 4 * C + k * C + cv * V;
+      vload<T, V>((const T*)br.z[k] + idx, a);
+      if (br.aff[k]) {
 #pragma unroll
-      for (int j = 0; j < V; j++) acc[j] += a[j] * wk[j];
+        for (int j = 0; j < V; j++) a[j] = to_f32(from_f32<T>(fmaxf(a[j] * sc[k][j] + sh[k][j], 0.f)));
+      }
+#pragma unroll
+      for (int j = 0; j < V; j++) acc[j] += a[j] * wk[k][j];
     }
-    vstore<T, V>(out + i * V, acc);
+    vstore<T, V>(out + idx, acc);
   }
 }
 
@@ -393,14 +410,16 @@ struct BranchBn {
   const float* gamma[4];   // [C] each; mean and rstd are rows 2 and 3 of the branch's [4][C] affine
   const float* beta[4];
 };
-constexpr int ST_N = 5;
+constexpr int ST_N_BWD = 5;
 
 // Workgroup = (branch k, sample b, pixel chunk r); thread = (channel vector cv, pixel lane pl) walking a
 // contiguous chunk.  partials[r][q][b][k*C + c]; fixed-order LDS tree.
-template <typename T, int V>
+// POOL: only sum a (g unused, NQ = 1) — the global average pool of the forward pass, scaled by `scale`.
+template <typename T, int V, bool POOL = false>
 __global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn bn, const T* __restrict__ g, int B,
                                                            int HW, int C, int rows, int chunk,
-                                                           float* __restrict__ partials) {
+                                                           float* __restrict__ partials, float scale = 1.f) {
+  constexpr int ST_N = POOL ? 1 : ST_N_BWD;
   extern __shared__ float red[];             // [PL][ST_N][C]
   const int CV = C / V, PL = TPB / CV;
   const int k = blockIdx.x & 3, r = (blockIdx.x >> 2) % rows, b = (blockIdx.x >> 2) / rows;
@@ -412,15 +431,17 @@ __global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn
 #pragma unroll
     for (int j = 0; j < V; j++) acc[q][j] = 0.f;
   if (pl < PL) {
-    float sc[V], sh[V], mu[V], rs[V], ga[V], be[V];
+    float sc[V], sh[V], mu[POOL ? 1 : V], rs[POOL ? 1 : V], ga[POOL ? 1 : V], be[POOL ? 1 : V];
 #pragma unroll
     for (int j = 0; j < V; j++) {
-      sc[j] = aff[c0 + j];
-      sh[j] = aff[C + c0 + j];
-      mu[j] = aff[2 * C + c0 + j];
-      rs[j] = aff[3 * C + c0 + j];
-      ga[j] = bn.gamma[k][c0 + j];
-      be[j] = bn.beta[k][c0 + j];
+      sc[j] = aff ? aff[c0 + j] : 1.f;
+      sh[j] = aff ? aff[C + c0 + j] : 0.f;
+      if constexpr (!POOL) {
+        mu[j] = aff[2 * C + c0 + j];
+        rs[j] = aff[3 * C + c0 + j];
+        ga[j] = bn.gamma[k][c0 + j];
+        be[j] = bn.beta[k][c0 + j];
+      }
     }
     const T* zk = (const T*)br.z[k];
     const int p1 = (r + 1) * chunk < HW ? (r + 1) * chunk : HW;
@@ -428,19 +449,24 @@ __global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn
     for (int p = r * chunk + pl; p < p1; p += PL) {
       const int64_t idx = ((int64_t)b * HW + p) * C + c0;
       float gv[V], zv[V];
-      vload<T, V>(g + idx, gv);
+      if constexpr (!POOL) vload<T, V>(g + idx, gv);
       vload<T, V>(zk + idx, zv);
 #pragma unroll
       for (int j = 0; j < V; j++) {
-        const float a = to_f32(from_f32<T>(fmaxf(zv[j] * sc[j] + sh[j], 0.f)));      // the activation as consumers read it
-        const float xh = (zv[j] - mu[j]) * rs[j];
-        const bool on = xh * ga[j] + be[j] > 0.f;                                    // the mask of the layer's dz kernel
-        const float dy = on ? gv[j] : 0.f;
-        acc[0][j] += a * gv[j];
-        acc[1][j] += dy;
-        acc[2][j] += dy * xh;
-        acc[3][j] += on ? 1.f : 0.f;
-        acc[4][j] += on ? xh : 0.f;
+        // the activation as consumers read it (a plain branch tensor has no affine)
+        const float a = aff ? to_f32(from_f32<T>(fmaxf(zv[j] * sc[j] + sh[j], 0.f))) : zv[j];
+        if constexpr (POOL) {
+          acc[0][j] += a;
+        } else {
+          const float xh = (zv[j] - mu[j]) * rs[j];
+          const bool on = xh * ga[j] + be[j] > 0.f;                                  // the mask of the layer's dz kernel
+          const float dy = on ? gv[j] : 0.f;
+          acc[0][j] += a * gv[j];
+          acc[1][j] += dy;
+          acc[2][j] += dy * xh;
+          acc[3][j] += on ? 1.f : 0.f;
+          acc[4][j] += on ? xh : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -453,11 +479,11 @@ __global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn
     float t = 0.f;
     for (int q = 0; q < PL; q++) t += red[q * ST_N * C + e];
     const int qq = e / C, c = e % C;
-    partials[(((int64_t)r * ST_N + qq) * B + b) * 4 * C + k * C + c] = t;
+    partials[(((int64_t)r * ST_N + qq) * B + b) * 4 * C + k * C + c] = t * scale;
   }
 }
 
-// stats [ST_N][B][4C] (+ w, ds [B][4C]) -> bn_sums [4][2][C] and the shift table ds/HW [B][4C]
+// stats [ST_N_BWD][B][4C] (+ w, ds [B][4C]) -> bn_sums [4][2][C] and the shift table ds/HW [B][4C]
 __global__ __launch_bounds__(TPB) void branch_bn_sums_kernel(const float* __restrict__ stats, const float* __restrict__ w,
                                                              const float* __restrict__ ds, float inv, int B, int C,
                                                              float* __restrict__ bn_sums, float* __restrict__ shift) {
@@ -640,18 +666,29 @@ template <typename T>
 int fuse_fwd_t(const Branches& br, int B, int HW, int C, const float* W1, const float* b1, const float* W2,
                const float* b2, float* s, float* h, float* w, void* out, void* workspace, hipStream_t st) {
   const int V = fuse_vec<T>(C, br, out, nullptr);
-  int rows;
-  launch_dot<T>(br, nullptr, B, HW, C, V, 1.0f / (float)HW, (float*)workspace, rows, st);
-  MIS_CHECK_LAUNCH("branch_dot_kernel");
+  const int rows = stats_rows(B, HW, C, V), chunk = (HW + rows - 1) / rows;
+  const size_t lds = (size_t)(TPB / (C / V)) * C * sizeof(float);
+  BranchBn none{};
+  if (V == VecOf<T>::N)
+    branch_stats_kernel<T, VecOf<T>::N, true><<<4 * B * rows, TPB, lds, st>>>(br, none, nullptr, B, HW, C, rows, chunk,
+                                                                            (float*)workspace, 1.0f / (float)HW);
+  else
+    branch_stats_kernel<T, 1, true><<<4 * B * rows, TPB, lds, st>>>(br, none, nullptr, B, HW, C, rows, chunk,
+                                                                    (float*)workspace, 1.0f / (float)HW);
+  MIS_CHECK_LAUNCH("branch_stats_kernel");
   launch_reduce_partials((const float*)workspace, rows, B * 4 * C, s, st);
   MIS_CHECK_LAUNCH("reduce_partials_kernel");
   mlp_fwd_kernel<<<B, TPB, (size_t)5 * C * sizeof(float), st>>>(s, W1, b1, W2, b2, C, h, w);
   MIS_CHECK_LAUNCH("mlp_fwd_kernel");
-  const int64_t n = (int64_t)B * HW * C;
+  // pixel chunks of the weighted sum: about 4096 workgroups, >= 8 pixels per thread
+  int wrows = HW / ((TPB / (C / V)) * 8);
+  if (wrows > (4096 + B - 1) / B) wrows = (4096 + B - 1) / B;
+  if (wrows < 1) wrows = 1;
+  const int wchunk = (HW + wrows - 1) / wrows;
   if (V == VecOf<T>::N)
-    wsum_fwd_kernel<T, VecOf<T>::N><<<ew_grid(n / V, TPB), TPB, 0, st>>>(br, w, B, HW, C, (T*)out);
+    wsum_fwd_kernel<T, VecOf<T>::N><<<B * wrows, TPB, 0, st>>>(br, w, B, HW, C, wrows, wchunk, (T*)out);
   else
-    wsum_fwd_kernel<T, 1><<<ew_grid(n, TPB), TPB, 0, st>>>(br, w, B, HW, C, (T*)out);
+    wsum_fwd_kernel<T, 1><<<B * wrows, TPB, 0, st>>>(br, w, B, HW, C, wrows, wchunk, (T*)out);
   MIS_CHECK_LAUNCH("wsum_fwd_kernel");
   return MIS_OK;
 }
@@ -698,20 +735,20 @@ int fuse_bwd_lazy_t(const Branches& br, const BranchBn& bn, const void* dout, in
   const int C4 = 4 * C;
   const int V = fuse_vec<T>(C, br, dout, nullptr);
   const int rows = stats_rows(B, HW, C, V), chunk = (HW + rows - 1) / rows;
-  // workspace: partial rows [rows][ST_N][B][4C] | stats [ST_N][B][4C] (plane 0 = dw) | g2 | ds [B][4C] | g1 [B][C]
+  // workspace: partial rows [rows][ST_N_BWD][B][4C] | stats [ST_N_BWD][B][4C] (plane 0 = dw) | g2 | ds [B][4C] | g1 [B][C]
   const size_t vec = align256((size_t)B * C4 * sizeof(float));
   float* partials = (float*)workspace;
-  float* stats = (float*)((char*)workspace + align256((size_t)rows * ST_N * B * C4 * sizeof(float)));
-  float* g2 = (float*)((char*)stats + align256((size_t)ST_N * B * C4 * sizeof(float)));
+  float* stats = (float*)((char*)workspace + align256((size_t)rows * ST_N_BWD * B * C4 * sizeof(float)));
+  float* g2 = (float*)((char*)stats + align256((size_t)ST_N_BWD * B * C4 * sizeof(float)));
   float* ds = (float*)((char*)g2 + vec);
   float* g1 = (float*)((char*)ds + vec);
-  const size_t lds = (size_t)(TPB / (C / V)) * ST_N * C * sizeof(float);
+  const size_t lds = (size_t)(TPB / (C / V)) * ST_N_BWD * C * sizeof(float);
   if (V == VecOf<T>::N)
     branch_stats_kernel<T, VecOf<T>::N><<<4 * B * rows, TPB, lds, st>>>(br, bn, (const T*)dout, B, HW, C, rows, chunk, partials);
   else
     branch_stats_kernel<T, 1><<<4 * B * rows, TPB, lds, st>>>(br, bn, (const T*)dout, B, HW, C, rows, chunk, partials);
   MIS_CHECK_LAUNCH("branch_stats_kernel");
-  launch_reduce_partials(partials, rows, ST_N * B * C4, stats, st);
+  launch_reduce_partials(partials, rows, ST_N_BWD * B * C4, stats, st);
   MIS_CHECK_LAUNCH("reduce_partials_kernel");
   mlp_bwd_sample_kernel<<<B, MLP_BWD_THREADS, (size_t)(5 * C + MLP_BWD_THREADS) * sizeof(float), st>>>(stats, w, h, W1, W2, C, g1, g2, ds);
   MIS_CHECK_LAUNCH("mlp_bwd_sample_kernel");
@@ -833,7 +870,8 @@ extern "C" {
 size_t mis_amsfn_workspace_bytes(int B, int HW, int C) {
   if (B < 1 || HW < 1 || C < 1) return 0;
   // the scalar layout has the most pixel rows
-  const int rows = dot_rows(B, HW, C, 1) > dot_rows(B, HW, C, 4) ? dot_rows(B, HW, C, 1) : dot_rows(B, HW, C, 4);
+  int rows = dot_rows(B, HW, C, 1) > dot_rows(B, HW, C, 4) ? dot_rows(B, HW, C, 1) : dot_rows(B, HW, C, 4);
+  if (stats_rows(B, HW, C, 1) > rows) rows = stats_rows(B, HW, C, 1);
   return align256((size_t)rows * B * 4 * C * sizeof(float)) + 4 * align256((size_t)B * 4 * C * sizeof(float));
 }
 
@@ -881,7 +919,7 @@ size_t mis_amsfn_lazy_workspace_bytes(int B, int HW, int C) {
   if (B < 1 || HW < 1 || C < 1) return 0;
   const int rows = stats_rows(B, HW, C, 1) > stats_rows(B, HW, C, 4) ? stats_rows(B, HW, C, 1) : stats_rows(B, HW, C, 4);
   const size_t plane = (size_t)B * 4 * C * sizeof(float);
-  return align256((size_t)rows * ST_N * plane) + align256(ST_N * plane) + 3 * align256(plane);
+  return align256((size_t)rows * ST_N_BWD * plane) + align256(ST_N_BWD * plane) + 3 * align256(plane);
 }
 
 int mis_amsfn_fuse_bwd_lazy(const void* const* z, const float* const* z_affine4, const float* const* bn_gamma,

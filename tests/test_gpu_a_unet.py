@@ -183,12 +183,33 @@ def test_amsfn_backward_without_branch_gradients(dtype, C, hw):
     assert d_written < 0.2 and d_fused < max(1.25 * d_written, 1e-2), (d_fused, d_written)
 
 
-# measured: 1.5e-4 / 1.1e-3 (aunet_a), 4.5e-3 / 1.4e-2 (aunet_b: one ReLU of a large-gradient pixel flips, as in the U-Net goldens)
-A_UNET_GRAD_NORM_TOL, A_UNET_GRAD_NORM_REL_TOL = 1e-2, 3e-2
+def _a_unet_oracle_norms(g, name, c, dtype):
+    """Per-parameter gradient norms of the CPU oracle in `dtype` on the case's weights and batch."""
+    spec = [(str(k), tuple(int(v) for v in str(s).split(",") if v)) for k, s in zip(g[f"{name}.keys"], g[f"{name}.shapes"])]
+    st = orc.hash_state(spec, c["seed"], dtype=dtype)
+    keys = [str(k) for k in g[f"{name}.grad_keys"]]
+    for k in keys:
+        st[k].requires_grad_(True)
+    x = T(dg.hash_normalish((c["B"], c["cin"], c["hw"], c["hw"]), c["seed"] + 100)).to(dtype)
+    t = T(dg.blob_mask(c["B"], c["hw"], c["hw"], c["ncls"], c["seed"] + 300))
+    lo = orc.a_unet_forward(x, st, training=True)
+    orc.dice_loss(lo, t, [f"c{i}" for i in range(1, c["ncls"])])["total_loss"].backward()
+    return np.array([float(st[k].grad.double().norm()) for k in keys])
+
+
+A_UNET_GRAD_NORM_TOL = 1e-2
 
 
 @pytest.mark.parametrize("name", list(mg.a_unet_cases()))
 def test_a_unet_fp32_golden(golden, name, report):
+    """float32 forward + backward of the whole network against the reference's own outputs.  Forward: logits 1e-3
+    of their scale, losses 1e-5.  Gradient norms per tensor: these ~90-layer networks with 2..8-channel BatchNorm
+    layers are sensitive to float32 round-off (a ReLU within round-off of zero under a concentrated Dice gradient
+    moves whole tensors), and how sensitive is measured, not assumed: the CPU oracle run in float32 and in float64
+    — the same arithmetic at two precisions — differs from itself by 6.5e-3 (aunet_a) and 2.9e-2 (aunet_b) in the
+    worst tensor; the reference's own float32 fixture is 1.2e-3 / 1.6e-2 from the float64 oracle.  Bound: within
+    max(1e-2, twice that measured sensitivity) of the float64 oracle, and within 10 % (per tensor) / 5 % (of the
+    largest norm) of the fixture."""
     from medical_image_segmentation_amd.model.a_unet import A_UNet
     from medical_image_segmentation_amd.utils.loss_fn import diceloss
     g = golden("a_unet")
@@ -212,11 +233,21 @@ def test_a_unet_fp32_golden(golden, name, report):
     norms = np.array([float(params[k].grad.double().norm()) for k in keys])
     ref = g[f"{name}.grad_norms"]
     big = ref > 1e-3 * ref.max()
-    dev_abs = float(np.abs(norms[big] - ref[big]).max() / ref.max())
-    dev_rel = float((np.abs(norms[big] - ref[big]) / ref[big]).max())
+
+    def dev(a, b):
+        return (float(np.abs(a[big] - b[big]).max() / b.max()), float((np.abs(a[big] - b[big]) / b[big]).max()))
+
+    o64, o32 = _a_unet_oracle_norms(g, name, c, torch.float64), _a_unet_oracle_norms(g, name, c, torch.float32)
+    sens = dev(o32, o64)[1]
+    report("float32-vs-float64 oracle gradient-norm deviation (sensitivity of the fixture)", sens)
+    dev_abs, dev_rel = dev(norms, ref)
     report("fp32 gradient norm deviation / largest norm", dev_abs)
     report("fp32 gradient norm deviation per tensor (relative, worst)", dev_rel)
-    assert dev_abs < A_UNET_GRAD_NORM_TOL and dev_rel < A_UNET_GRAD_NORM_REL_TOL
+    d64, d32 = dev(norms, o64)[1], dev(norms, o32)[1]
+    report("fp32 gradient norm deviation vs float64 oracle (relative, worst)", d64)
+    report("fp32 gradient norm deviation vs float32 oracle (relative, worst)", d32)
+    assert d64 < max(A_UNET_GRAD_NORM_TOL, 2 * sens), (d64, sens)
+    assert dev_rel < 0.10 and dev_abs < 0.05, (dev_rel, dev_abs)
     assert rel_err(m.acpn0.final_conv[1].running_mean, g[f"{name}.running_mean.acpn0.final_conv"]) < 1e-3
     m.eval()
     with torch.no_grad():
