@@ -195,7 +195,7 @@ int mis_wgrad_reduce_multi(const mis_wgrad_reduce_job* jobs, int n_jobs, mis_str
 
 int mis_conv3x3_dilated_supported(int dtype, int B, int H, int W, int Cin, int Cout, int dilation) {
   if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
-  if (dilation < 1 || dilation > 3 || force_direct()) return 0;
+  if (dilation < 0 || dilation > 3 || force_direct()) return 0;      // 0: only the centre tap is non-zero (a 1x1 conv)
   return (use_mfma(dtype, Cin, Cout) && use_mfma(dtype, Cout, Cin) && conv3x3_mfma_supported(dtype, B, H, W, Cin, Cout) &&
           conv3x3_mfma_supported(dtype, B, H, W, Cout, Cin) && conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout))
              ? 1 : 0;
@@ -214,7 +214,7 @@ int mis_conv3x3_dilated_fwd(const void* x, const float* x_affine, const void* w_
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_dilated_fwd: bad dtype %d", dtype);
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 1 && Cout >= 1 && (int64_t)B * H * W < ((int64_t)1 << 31),
               "conv3x3_dilated_fwd: bad shape");
-  if (dilation < 1 || dilation > 3 || force_direct() || !use_mfma(dtype, Cin, Cout)) {
+  if (dilation < 0 || dilation > 3 || force_direct() || !use_mfma(dtype, Cin, Cout)) {
     mis_set_error("conv3x3_dilated_fwd: %d -> %d channels with dilation %d is not taken by the matrix-core kernels",
                   Cin, Cout, dilation);
     return MIS_ERR_UNSUPPORTED;

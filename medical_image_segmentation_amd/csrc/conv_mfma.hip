@@ -272,6 +272,13 @@ __global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_
   constexpr int G = Mf<T>::G;
   using Frag = typename Mf<T>::Frag;
   constexpr int NS = nsteps_of(CPG);
+  // DIL == 0: only the centre tap of the 3x3 weights is non-zero (a 1x1 conv carried by this kernel): no halo,
+  // and of the 9 steps of a chunk (a step is a tap with 4 groups per position) only the centre one is staged
+  // and multiplied
+  constexpr bool CENTER = (DIL == 0);
+  static_assert(!CENTER || CPG == 4, "the centre-tap form needs a step to be exactly one tap");
+  constexpr int NSW = CENTER ? 1 : NS;     // steps staged and multiplied per chunk ...
+  constexpr int S0 = CENTER ? 4 : 0;       // ... starting at this one of the packed image
   constexpr int KC = CPG * G;
   constexpr int MT = fwd_mt(NT, CPG);      // tile rows per wave
   constexpr int MX = fwd_mx(NT, CPG), MY = MT / MX;      // a wave's segments: MY rows x MX side by side
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_
   constexpr int HP = (TH + 2 * DIL) * HW_;               // halo positions
   constexpr int HALO_VECS = HP * CPG;
   constexpr int HALO_IT = (HALO_VECS + CM_THREADS - 1) / CM_THREADS;
-  constexpr int W_VECS = NS * NT * 64;
+  constexpr int W_VECS = NSW * NT * 64;
   constexpr int W_IT = (W_VECS + CM_THREADS - 1) / CM_THREADS;
   constexpr bool PAIR = (sizeof(T) == 2 && NT >= 2);   // 16-byte stores from lane pairs (host: Cout % 8 == 0)
   constexpr int NSTORE = PAIR ? NT / 2 : NT;
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_
       const unsigned v = (unsigned)tid_l + i * CM_THREADS;                                               \
       const unsigned s_ = (NT * 64 == CM_THREADS) ? (unsigned)i : v / (NT * 64);                         \
       const unsigned rem = (NT * 64 == CM_THREADS) ? (unsigned)tid_l : v % (NT * 64);                    \
-      const unsigned off = ((((unsigned)(CHUNK) * NS + s_) * (unsigned)nt_total + (unsigned)n0) * 64 + rem) * 16; \
+      const unsigned off = ((((unsigned)(CHUNK) * NS + S0 + s_) * (unsigned)nt_total + (unsigned)n0) * 64 + rem) * 16; \
       wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (live_ && v < (unsigned)W_VECS) ? (int)off : (int)OOB, 0, 0); \
     }                                                                                                    \
   }
@@ -649,8 +656,8 @@ __global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_
         /* fragments of step s+1 are fetched from LDS while the MFMAs of step s run (two register */     \
         /* sets); the scheduling barrier keeps the compiler from hoisting every step's reads up */       \
         LOAD_FRAGS(0, 0)                                                                                 \
-        _Pragma("unroll") for (int s = 0; s < ((MIS_DBG & 8) ? 1 : NS); s++) {                           \
-          if (s + 1 < NS) LOAD_FRAGS(s + 1, (s + 1) & 1)                                                 \
+        _Pragma("unroll") for (int s = 0; s < ((MIS_DBG & 8) ? 1 : NSW); s++) {                          \
+          if (s + 1 < NSW) LOAD_FRAGS(s + 1, (s + 1) & 1)                                                \
           if constexpr (WS || MIS_PIN_FRAGS) __builtin_amdgcn_sched_barrier(0); /* reads first: a step of MFMAs covers their latency */ \
           _Pragma("unroll") for (int n = 0; n < NT; n++)                                                 \
             _Pragma("unroll") for (int m = 0; m < MT; m++)                                               \
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(WS ? 2 * CM_THREADS : CM_THREADS, WS ? 1 : fwd_min_
         }                                                                                                \
       } else {                                                                                           \
         /* widest variants: one fragment set, the compiler interleaves reads and MFMAs itself */         \
-        _Pragma("unroll") for (int s = 0; s < NS; s++) {                                                 \
+        _Pragma("unroll") for (int s = 0; s < NSW; s++) {                                                \
           LOAD_FRAGS(s, 0)                                                                               \
           _Pragma("unroll") for (int n = 0; n < NT; n++)                                                 \
             _Pragma("unroll") for (int m = 0; m < MT; m++) mfma_step(wf[0][n], xa[0][m], acc[m][n]);     \
@@ -1000,6 +1007,9 @@ void launch_fwd_k(const FwdPlan& p, const FwdArgs& a, hipStream_t st) {
              : a.dil == 2 ? conv3x3_mfma_kernel<T, NT, CPG, false, 2>
              : a.dil == 3 ? conv3x3_mfma_kernel<T, NT, CPG, false, 3>
                           : conv3x3_mfma_kernel<T, NT, CPG, false, 1>;
+  if constexpr (CPG == 4) {
+    if (a.dil == 0 && !a.bnz) kfn = conv3x3_mfma_kernel<T, NT, 4, false, 0>;     // centre tap only
+  }
   int threads = CM_THREADS;
   if constexpr (CPG == 4 && NT >= 2) {
     if (p.ws) {
@@ -1033,10 +1043,13 @@ int run_fwd(const ConvIn& in, const void* wp, const float* bias, int B, int H, i
             int dil = 1) {
   FwdPlan p;
   const int Cin = in.channels(), Cout = out.channels();
-  if (dil < 1 || dil > 3 || (dil != 1 && bnz)) {
-    mis_set_error("conv3x3_mfma: dilation %d not supported here (1..3; the fused BatchNorm sums only with 1)", dil);
+  if (dil < 0 || dil > 3 || (dil != 1 && bnz)) {
+    mis_set_error("conv3x3_mfma: dilation %d not supported here (0..3; the fused BatchNorm sums only with 1)", dil);
     return MIS_ERR_UNSUPPORTED;
   }
+  // dil == 0: the caller states that only the centre tap is non-zero; shapes whose K steps span several taps run
+  // the full 3x3 (same result)
+  if (dil == 0 && !(plan_fwd<T>(B, H, W, Cin, Cout, p, in.Ca, out.Ca, 0) && p.CPG == 4)) dil = 1;
   if (!plan_fwd<T>(B, H, W, Cin, Cout, p, in.Ca, out.Ca, dil)) {
     mis_set_error("conv3x3_mfma: unsupported shape Cin=%d+%d Cout=%d+%d", in.Ca, in.Cb, out.Ca, out.Cb);
     return MIS_ERR_UNSUPPORTED;
@@ -1077,8 +1090,10 @@ bool conv3x3_mfma_split_supported(int dtype, int Cin, int Ca, int Cb) {
 
 int conv3x3_mfma_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout, int dil) {
   FwdPlan p;
-  const bool ok = dtype == MIS_BF16 ? plan_fwd<bf16>(B, H, W, Cin, Cout, p, -1, -1, dil)
-                                    : plan_fwd<float>(B, H, W, Cin, Cout, p, -1, -1, dil);
+  bool ok = dtype == MIS_BF16 ? plan_fwd<bf16>(B, H, W, Cin, Cout, p, -1, -1, dil)
+                              : plan_fwd<float>(B, H, W, Cin, Cout, p, -1, -1, dil);
+  if (dil == 0 && !(ok && p.CPG == 4))       // (the centre-tap form falls back to the full 3x3, as run_fwd does)
+    ok = dtype == MIS_BF16 ? plan_fwd<bf16>(B, H, W, Cin, Cout, p) : plan_fwd<float>(B, H, W, Cin, Cout, p);
   return ok ? p.grid_x : 0;
 }
 

@@ -684,6 +684,7 @@ class BranchGradLink:
         self.ptr = self.version = -1
 
 
+CENTER_TAP_CONVS = True  # 1x1 convs carried as 3x3 multiply their centre tap only (module attribute: the tests compare)
 FUSE_AMSFN_BWD = True    # (module attribute: the tests compare with the form that writes the four branch gradients)
 
 
@@ -704,6 +705,8 @@ class ConvBnReluFn(torch.autograd.Function):
     def forward(ctx, x, x_ss, x2, x2_ss, weight, bias, gamma, beta, running_mean, running_var, nbt, training, eps,
                 momentum, relu=True, dilation=1, head=None, link=None):
         """x2 (optional, lazy or plain like x): the input is the virtual concatenation [x | x2].
+        dilation 0: the weight is a 1x1 conv embedded in a 3x3 (pointwise_as_3x3): forward and data gradient then
+        multiply the centre tap only.
         relu=False: BatchNorm without a ReLU of its own (ResDConv's `c1` and `cbr3`, modules.py:432-433,
         444-445): ss is then the affine of bn(z) and the incoming gradient is that of the BatchNorm
         output; only a consumer that knows (functional.add_bn_relu) may read such a pair.
@@ -728,7 +731,10 @@ class ConvBnReluFn(torch.autograd.Function):
             wf, ctx.wt = pack_weights_pair(weight.detach(), x.dtype)
         else:
             wf, ctx.wt = pack_weights(weight.detach(), x.dtype), None
-        if dilation != 1 and not query("mis_conv3x3_dilated_supported", _dt(x), B, H, W, Cin, Cout, dilation):
+        if dilation == 0 and (x2 is not None or not CENTER_TAP_CONVS
+                              or not query("mis_conv3x3_dilated_supported", _dt(x), B, H, W, Cin, Cout, 0)):
+            dilation = 1            # (0 is a statement about the weights — only the centre tap is non-zero — not a need)
+        if dilation > 1 and not query("mis_conv3x3_dilated_supported", _dt(x), B, H, W, Cin, Cout, dilation):
             raise RuntimeError(f"dilated conv {Cin}->{Cout} (dilation {dilation}) is not taken by the matrix-core kernels")
         z, stats = conv3x3_raw(x, wf, bias.detach() if bias is not None else None, Cout,
                                "partial" if training else False, x_ss, x2, x2_ss, dilation)
@@ -843,12 +849,13 @@ class ConvBnReluFn(torch.autograd.Function):
 
         # weight gradient first, data gradient last: what consumes the data gradient runs right behind it
         dw = None
+        wdil = max(dil, 1)          # (a centre-tap layer's weight gradient is the plain 3x3 one)
         if rows is not None:
-            dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=dil,
+            dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=wdil,
                                           defer=(ctx.bias_ref is not None and ctx.bias_ref() is not None
                                                  and can_defer_wgrad(weight, ctx.bias_ref())))
         elif want_dw:
-            dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=dil, defer=can_defer_wgrad(weight))
+            dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=wdil, defer=can_defer_wgrad(weight))
         data_gradient()
         return dx, None, dx2, None, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
@@ -1067,13 +1074,14 @@ class UpsampleFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # AMSFN pieces (model/utils/modules.py:791-871)
 # ---------------------------------------------------------------------------
-def conv_bn_relu_w(x, x_ss, weight, bias, bn, training, link=None):
+def conv_bn_relu_w(x, x_ss, weight, bias, bn, training, link=None, pointwise=False):
     """Like `conv_bn_relu` with an explicit [Cout, Cin, 3, 3] weight / bias (any autograd tensors).
-    link: a BranchGradLink shared with the AmsfnFuseFn that is the only consumer of (z, ss)."""
+    link: a BranchGradLink shared with the AmsfnFuseFn that is the only consumer of (z, ss).
+    pointwise: `weight` came from pointwise_as_3x3 (only its centre tap is non-zero)."""
     momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
     return ConvBnReluFn.apply(x, x_ss, None, None, weight, bias, bn.weight, bn.bias, bn.running_mean,
                               bn.running_var, bn.num_batches_tracked, bool(training), float(bn.eps), float(momentum),
-                              True, 1, None, link)
+                              True, 0 if pointwise else 1, None, link)
 
 
 def pointwise_as_3x3(weight):

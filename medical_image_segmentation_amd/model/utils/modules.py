@@ -119,14 +119,14 @@ class AMSFN(nn.Module):
         links = [F_.BranchGradLink() for _ in range(4)] if self.training else [None] * 4
         pooled = F_.MaxPool3x3Fn.apply(x1, x_ss)
         c1 = F_.conv_bn_relu_w(pooled, None, F_.pointwise_as_3x3(self.conv1x1[1].weight), self.conv1x1[1].bias,
-                               self.conv1x1[2], self.training, links[0])
+                               self.conv1x1[2], self.training, links[0], pointwise=True)
         c2 = self._dw_chain(self.cbr1, x2, x_ss, links[1])
         c3 = self._dw_chain(self.cbr2, x3, x_ss, links[2])
         c4 = self._dw_chain(self.cbr3, x4, x_ss, links[3])
         fused = F_.AmsfnFuseFn.apply(*c1, *c2, *c3, *c4, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
                                      self.mlp[2].bias, links if self.training else None)
         return F_.conv_bn_relu_w(fused, None, F_.pointwise_as_3x3(self.final_conv[0].weight),
-                                 self.final_conv[0].bias, self.final_conv[1], self.training)
+                                 self.final_conv[0].bias, self.final_conv[1], self.training, pointwise=True)
 
     def forward(self, x):
         z, ss = self.forward_lazy(F_.to_act(x))
@@ -166,7 +166,7 @@ class ResDConv(nn.Module):
         """(x, x_ss) [| (x2, x2_ss)] lazy or plain -> the block's activation (a plain tensor)."""
         t = self.training
         re = F_.conv_bn(x, x_ss, F_.pointwise_as_3x3(self.c1[0].weight), self.c1[0].bias, self.c1[1], t, relu=False,
-                        x2=x2, x2_ss=x2_ss)
+                        dilation=0, x2=x2, x2_ss=x2_ss)           # (0: centre tap only, where the kernels take it)
         y = F_.conv_bn(x, x_ss, self.cbr1[0].weight, self.cbr1[0].bias, self.cbr1[1], t, x2=x2, x2_ss=x2_ss)
         y = F_.conv_bn(*y, self.cbr2[0].weight, self.cbr2[0].bias, self.cbr2[1], t, dilation=2)
         y = F_.conv_bn(*y, self.cbr3[0].weight, self.cbr3[0].bias, self.cbr3[1], t, relu=False, dilation=3)
