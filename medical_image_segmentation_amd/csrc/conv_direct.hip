@@ -158,26 +158,33 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_direct_kernel(
 // ---------------------------------------------------------------------------------
 constexpr int F_TW = 64, F_TH = 16;
 
-template <typename T, int CIN>
+// NSL > 1 (no statistics wanted, Cout <= NSL * CO_T): one workgroup computes all NSL channel slices of its
+// tiles from one staged halo, slice after slice, so a pixel's 16-byte pieces are stored back to back by the
+// same lane (with one slice per workgroup, grid.y, they arrive from different workgroups at different times:
+// measured 339 us for 3 -> 32 channels at 16 x 512^2, a quarter of the write rate).
+template <typename T, int CIN, int NSL = 1>
 __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
     const T* __restrict__ x, const T* __restrict__ wp /*[9][Cout][CIN]*/, const float* __restrict__ bias,
     T* __restrict__ z, float* __restrict__ partials /*[gridDim.x][2][Cout] or null*/, int B, int H, int W, int Cout,
     const float* __restrict__ in_aff, int tiles_x, int tiles_y, int n_tiles) {
-  __shared__ __attribute__((aligned(16))) float wl[9 * CIN][CO_T];
+  __shared__ __attribute__((aligned(16))) float wl[NSL][9 * CIN][CO_T];
   __shared__ float red[2 * CO_T * (CD_THREADS / 64)];
   __shared__ float halo[CIN][F_TH + 2][F_TW + 2];
+  __shared__ float bl[NSL][CO_T];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int co0 = blockIdx.y * CO_T;
-  for (int i = tid; i < 9 * CIN * CO_T; i += CD_THREADS) {
-    const int j = i % CO_T, k = i / CO_T, ci = k % CIN, tap = k / CIN;
-    wl[k][j] = (co0 + j < Cout) ? to_f32(wp[((int64_t)tap * Cout + co0 + j) * CIN + ci]) : 0.f;
+  const int co_base = NSL > 1 ? 0 : blockIdx.y * CO_T;
+  for (int i = tid; i < NSL * 9 * CIN * CO_T; i += CD_THREADS) {
+    const int j = i % CO_T, k = (i / CO_T) % (9 * CIN), sl = i / (CO_T * 9 * CIN), ci = k % CIN, tap = k / CIN;
+    const int co = co_base + sl * CO_T + j;
+    wl[sl][k][j] = (co < Cout) ? to_f32(wp[((int64_t)tap * Cout + co) * CIN + ci]) : 0.f;
   }
-  float bv[CO_T], st[2 * CO_T];
+  for (int i = tid; i < NSL * CO_T; i += CD_THREADS) {
+    const int co = co_base + i;
+    bl[i / CO_T][i % CO_T] = (bias && co < Cout) ? bias[co] : 0.f;
+  }
+  float st[2 * CO_T];
 #pragma unroll
-  for (int j = 0; j < CO_T; j++) {
-    bv[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
-    st[j] = st[CO_T + j] = 0.f;
-  }
+  for (int j = 0; j < CO_T; j++) st[j] = st[CO_T + j] = 0.f;
   float asc[CIN], ash[CIN];
 #pragma unroll
   for (int c = 0; c < CIN; c++) {
@@ -232,14 +239,18 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
       for (int rr = 0; rr < 6; rr++)
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) xv[c][rr][kx] = halo[c][4 * wv + rr][lane + kx];
+#pragma unroll 1
+    for (int sl = 0; sl < NSL; sl++) {
+    const int co0 = co_base + sl * CO_T;
+    if (NSL > 1 && co0 >= Cout) break;                 // (3 slices run in the 4-slice instantiation)
     float acc[4][CO_T];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int j = 0; j < CO_T; j++) acc[r][j] = bv[j];
+      for (int j = 0; j < CO_T; j++) acc[r][j] = bl[sl][j];
 #pragma unroll
     for (int k = 0; k < 9 * CIN; k++) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[k][0]), w1 = *reinterpret_cast<const f32x4*>(&wl[k][4]);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[sl][k][0]), w1 = *reinterpret_cast<const f32x4*>(&wl[sl][k][4]);
       const int tap = k / CIN, c = k % CIN;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -278,8 +289,10 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
         }
       }
     }
+    }   // slices
   }
-  if (partials) {
+  if (partials && NSL == 1) {
+    const int co0 = co_base;
     __syncthreads();
     block_sum<2 * CO_T>(st, red);
     if (tid < 2 * CO_T) {
@@ -1020,11 +1033,25 @@ int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const
 #define FIRST_LAUNCH(TT, CIN)                                                                               \
   conv3x3_first_kernel<TT, CIN><<<grid, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)wp, bias, (TT*)z, partials, B, \
                                                              H, W, Cout, in_aff, ftx, fty, B * ftx * fty)
-    if (dtype == MIS_F32) {
+#define FIRST_ALL(TT, CIN, NSL_)                                                                            \
+  conv3x3_first_kernel<TT, CIN, NSL_><<<grid.x, CD_THREADS, 0, st>>>((const TT*)x, (const TT*)wp, bias, (TT*)z,    \
+                                                                     nullptr, B, H, W, Cout, in_aff, ftx, fty,      \
+                                                                     B * ftx * fty)
+    // no statistics and 2..4 channel slices (RDAM_UNet.encoder1, a bare 3 -> 32 conv, model/rdam_unet.py:21):
+    // all slices from one workgroup
+    const int nsl = cdiv(Cout, CO_T);
+    if (!partials && Cin == 3 && nsl >= 2 && nsl <= 4) {
+      if (dtype == MIS_F32) {
+        if (nsl == 2) FIRST_ALL(float, 3, 2); else FIRST_ALL(float, 3, 4);
+      } else {
+        if (nsl == 2) FIRST_ALL(bf16, 3, 2); else FIRST_ALL(bf16, 3, 4);
+      }
+    } else if (dtype == MIS_F32) {
       if (Cin == 1) FIRST_LAUNCH(float, 1); else FIRST_LAUNCH(float, 3);
     } else {
       if (Cin == 1) FIRST_LAUNCH(bf16, 1); else FIRST_LAUNCH(bf16, 3);
     }
+#undef FIRST_ALL
 #undef FIRST_LAUNCH
   } else {
     // narrow outputs take fewer channels per thread

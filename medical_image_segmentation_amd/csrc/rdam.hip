@@ -134,11 +134,16 @@ __global__ void mdam_sums_finalize_kernel(const float* __restrict__ partial, int
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, c = i % C;
+  // (row k outermost: the nine loads of a row are independent, so they are in flight together; the sums are
+  // still added in row order)
   double r[9];
-  for (int q = 0; q < 9; q++) {
-    double s = 0.0;
-    for (int k = 0; k < nblk; k++) s += (double)partial[(((int64_t)b * nblk + k) * 9 + q) * C + c];
-    r[q] = s;
+#pragma unroll
+  for (int q = 0; q < 9; q++) r[q] = 0.0;
+#pragma unroll 4
+  for (int k = 0; k < nblk; k++) {
+    const float* row = partial + ((int64_t)b * nblk + k) * 9 * C + c;
+#pragma unroll
+    for (int q = 0; q < 9; q++) r[q] += (double)row[q * C];
   }
   const double T = r[0], R0 = r[1], RL = r[2], C0 = r[3], CL = r[4], k00 = r[5], k0L = r[6], kL0 = r[7], kLL = r[8];
   // excluded row / column per tap index: 0 -> the LAST one, 1 -> none, 2 -> the FIRST one
@@ -239,9 +244,18 @@ __global__ void rows_sum_kernel(const float* __restrict__ partial, int nblk, int
   const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (b, c)
   if (i >= n_out) return;
   const int b = i / C, c = i % C;
-  double s = 0.0;
-  for (int k = 0; k < nblk; k++) s += (double)partial[((int64_t)b * nblk + k) * C + c];
-  out[i] = (float)s;
+  // four interleaved partial sums (rows k = j mod 4), combined in a fixed order: four loads in flight
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = 0;
+  for (; k + 3 < nblk; k += 4) {
+    const float* row = partial + ((int64_t)b * nblk + k) * C + c;
+    s0 += (double)row[0];
+    s1 += (double)row[C];
+    s2 += (double)row[2 * (int64_t)C];
+    s3 += (double)row[3 * (int64_t)C];
+  }
+  for (; k < nblk; k++) s0 += (double)partial[((int64_t)b * nblk + k) * C + c];
+  out[i] = (float)((s0 + s1) + (s2 + s3));
 }
 
 inline int rd_blocks(int64_t HW, int PR) {

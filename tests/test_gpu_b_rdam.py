@@ -78,6 +78,37 @@ def test_dilated_conv_kernels(dtype, dil, shape, lazy):
     assert rel_err(dw, dwo) < (2e-4 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 32, 21, 70), (1, 3, 16, 16, 64), (2, 3, 24, 9, 9), (1, 3, 8, 33, 130),
+                                   (1, 1, 32, 17, 40), (2, 1, 16, 8, 8), (1, 3, 40, 12, 12)])
+def test_bare_conv_image_facing(dtype, shape):
+    """nn.Conv2d(Cin, Cout, 3, padding=1) with nothing after it on the image (RDAM_UNet.encoder1,
+    model/rdam_unet.py:21): 1 or 3 input channels into 1..5 slices of 8 output channels — all slices from one
+    workgroup, the strip kernel for one input channel, and the per-slice form — against torch's conv2d
+    (float32: 2e-5 / 2e-4; bfloat16: 1e-2 / 2e-2 of each tensor's scale)."""
+    from medical_image_segmentation_amd import functional as F_
+    B, Ci, Co, H, W = shape
+    g = torch.Generator().manual_seed(Ci * 100 + Co)
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1).to(DEV)
+    x0 = torch.randn(B, Ci, H, W, generator=g).to(DEV)
+    gy = torch.randn(B, Co, H, W, generator=g).to(DEV)
+    x = x0.clone().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    z = F_.Conv3x3Fn.apply(x, None, None, None, conv.weight, conv.bias)
+    z.backward(gy.to(dtype).contiguous(memory_format=torch.channels_last))
+    got = (z.detach().float(), x.grad.float(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.zero_grad()
+    xr = x0.to(dtype).double().requires_grad_(True)
+    wq = conv.weight.detach().to(dtype).double().requires_grad_(True)       # the kernels multiply weights stored in `dtype`
+    bq = conv.bias.detach().double().requires_grad_(True)
+    zr = torch.nn.functional.conv2d(xr, wq, bq, padding=1)
+    zr.backward(gy.to(dtype).double())
+    tol, gtol = (2e-5, 2e-4) if dtype == torch.float32 else (1e-2, 2e-2)
+    assert rel_err(got[0], zr) < tol
+    assert rel_err(got[1], xr.grad) < gtol
+    assert rel_err(got[2], wq.grad) < gtol
+    assert rel_err(got[3], bq.grad) < gtol
+
+
 @pytest.mark.parametrize("name", list(mg.rdam_block_cases()))
 def test_rdam_blocks_golden(golden, name):
     from medical_image_segmentation_amd.model.utils.attention import MDAM
