@@ -998,7 +998,7 @@ int conv3x3_direct_fwd(const void* x, const float* in_aff, const void* wp, const
     case 4: KERNEL<TT, VV, 4><<<grid.x, CD_THREADS, 0, st>>>(__VA_ARGS__); break;           \
     default: KERNEL<TT, VV, 8><<<grid.x, CD_THREADS, 0, st>>>(__VA_ARGS__); break;          \
   }
-  if (Cin == 1 && small32 && vecs(Cout, z)) {
+  if (Cin == 1 && Cout >= 16 && small32 && vecs(Cout, z)) {      // (8 channels: the LDS-tiled kernel below is faster, 32 vs 46 us)
     const int cv = vecs(Cout, z);
     grid.x = conv3x3_direct_stats_rows(n_pix, B, H, W, Cin, Cout);
 #define FROM1(TT, VV, CVV)                                                                                              \

@@ -63,20 +63,16 @@ class A_UNet(nn.Module):
             raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
         pool, noise, up = F_.MaxPool2x2Fn.apply, F_.dropout2d_noise, UNet._up
         x = F_.to_act(x, self._dtype())
-        # an encoder output is read by its AMSFN block and by the decoder's skip connection: two aliases whose
-        # gradients meet in one kernel (which also emits the encoder layer's BatchNorm-backward sums)
-        def two(e):
-            a, b = F_.fan_out(e[0], e[1], 2)
-            return (a, e[1]), (b, e[1])
+        # an encoder output is read by the four branches of its AMSFN block and by the decoder's skip connection:
+        # five aliases whose gradients meet in one kernel (which also emits the encoder layer's BatchNorm-backward sums)
+        def block(acpn, e):
+            *four, skip = F_.fan_out(e[0], e[1], 5)
+            return acpn.forward_lazy(None, e[1], aliases=four), (skip, e[1])
 
-        e1, s1 = two(self.encoder1.forward_lazy(x))
-        a = self.acpn0.forward_lazy(*e1, input_read_elsewhere=True)
-        e2, s2 = two(self.encoder2.forward_lazy(pool(*a, noise(self.encoder_dropout1, a[0]))))
-        a = self.acpn1.forward_lazy(*e2, input_read_elsewhere=True)
-        e3, s3 = two(self.encoder3.forward_lazy(pool(*a, noise(self.encoder_dropout2, a[0]))))
-        a = self.acpn2.forward_lazy(*e3, input_read_elsewhere=True)
-        e4, s4 = two(self.encoder4.forward_lazy(pool(*a, noise(self.encoder_dropout3, a[0]))))
-        a = self.acpn3.forward_lazy(*e4, input_read_elsewhere=True)
+        a, s1 = block(self.acpn0, self.encoder1.forward_lazy(x))
+        a, s2 = block(self.acpn1, self.encoder2.forward_lazy(pool(*a, noise(self.encoder_dropout1, a[0]))))
+        a, s3 = block(self.acpn2, self.encoder3.forward_lazy(pool(*a, noise(self.encoder_dropout2, a[0]))))
+        a, s4 = block(self.acpn3, self.encoder4.forward_lazy(pool(*a, noise(self.encoder_dropout3, a[0]))))
         c5 = self.center_conv.forward_lazy(pool(*a, noise(self.encoder_dropout4, a[0])))
         d = self.acpn5.forward_lazy(*up(self.decoder1, *c5, *s4, noise(self.bottleneck_dropout, c5[0])))
         d = self.acpn6.forward_lazy(*up(self.decoder2, *d, *s3, noise(self.decoder_dropout1, d[0])))

@@ -110,11 +110,13 @@ class AMSFN(nn.Module):
                                         link if i + 3 >= len(seq) else None)
         return x, x_ss
 
-    def forward_lazy(self, x, x_ss=None, input_read_elsewhere=False):
+    def forward_lazy(self, x, x_ss=None, input_read_elsewhere=False, aliases=None):
         """(x, x_ss) lazy or plain activation -> lazy (z, ss) of the final conv.  The input feeds four branches:
         their gradients are summed in one kernel (functional.fan_out), which also produces the BatchNorm-backward
-        sums of the layer that wrote x unless the caller says that x has further readers."""
-        x1, x2, x3, x4 = F_.fan_out(x, x_ss, 4, bn_sums=not input_read_elsewhere)
+        sums of the layer that wrote x unless the caller says that x has further readers.
+        aliases: four aliases of x from a fan-out the caller made itself (one that also serves x's other readers,
+        so all gradients of x meet in one kernel); x is then not used."""
+        x1, x2, x3, x4 = aliases if aliases is not None else F_.fan_out(x, x_ss, 4, bn_sums=not input_read_elsewhere)
         # each branch output is read by the fusion node alone: its gradient is never written (functional.BranchGradLink)
         links = [F_.BranchGradLink() for _ in range(4)] if self.training else [None] * 4
         pooled = F_.MaxPool3x3Fn.apply(x1, x_ss)

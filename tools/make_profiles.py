@@ -12,9 +12,10 @@ tag, rnd = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 28
 src = os.path.join("gpurun_out", tag)
 shutil.copy(os.path.join(src, "bench.json"), f"profiles/{rnd}_bench_{tag}.json")
-with open(f"profiles/{rnd}_pmc_traffic.json", "w") as f:
-    subprocess.check_call([sys.executable, "tools/pmc_traffic.py", os.path.join(src, "pmc/pass1/p_results.db"),
-                           os.path.join(src, "pmc/pass2/p_results.db")], stdout=f)
+if os.path.exists(os.path.join(src, "pmc/pass1/p_results.db")):       # (a run without counter passes keeps the other run's file)
+    with open(f"profiles/{rnd}_pmc_traffic.json", "w") as f:
+        subprocess.check_call([sys.executable, "tools/pmc_traffic.py", os.path.join(src, "pmc/pass1/p_results.db"),
+                               os.path.join(src, "pmc/pass2/p_results.db")], stdout=f)
 rows = list(csv.DictReader(open(os.path.join(src, "prof/p_kernel_stats.csv"))))
 out, tot = [], 0.0
 for r in rows:
