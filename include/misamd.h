@@ -466,6 +466,23 @@ int mis_dwconv_compose_fwd(const float* P, const float* D, const float* bd, cons
                            float* W, float* b, mis_stream_t stream);
 int mis_dwconv_compose_bwd(const float* P, const float* D, const float* bd, const float* dW, const float* db, int Cout,
                            int Cin, float* dP, float* dD, float* dbd, mis_stream_t stream);
+/* The forward composition of MANY layers in one launch (a network with 48 DWConv     */
+/* layers otherwise pays 48 launches of a few microseconds per step): job j owns the   */
+/* workgroups [first_block, first_block + n_blocks) of the launch; `jobs` is a DEVICE  */
+/* array.  D == NULL: the layer is a plain 1x1 conv (AMSFN.conv1x1 / final_conv,        */
+/* modules.py:801,838) and W is P at the centre tap, zero elsewhere; b is then not      */
+/* written (the conv takes the 1x1 conv's own bias).  Same expressions as               */
+/* mis_dwconv_compose_fwd: identical results.                                           */
+typedef struct {
+  const float* P;     /* [Cout][Cin] */
+  const float* D;     /* [Cin][9] or NULL */
+  const float* bd;    /* [Cin] (D != NULL) */
+  const float* bp;    /* [Cout] (D != NULL) */
+  float* W;           /* [Cout][Cin][3][3] */
+  float* b;           /* [Cout] (D != NULL) */
+  int Cout, Cin, first_block, n_blocks;
+} mis_compose_job;
+int mis_dwconv_compose_multi(const mis_compose_job* jobs, int n_jobs, int total_blocks, mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* RDAM_UNet (model/rdam_unet.py:7-115): what is not a convolution.              */

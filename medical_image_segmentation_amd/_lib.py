@@ -93,6 +93,7 @@ PROTOTYPES = {
     "mis_maxpool3x3s1_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_sum_gradients_workspace_bytes": (_sz, [_i]),
     "mis_sum_gradients": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_dwconv_compose_multi": (_i, [_vp, _i, _i, _vp]),
     "mis_amsfn_workspace_bytes": (_sz, [_i, _i, _i]),
     "mis_amsfn_lazy_workspace_bytes": (_sz, [_i, _i, _i]),
     "mis_amsfn_fuse_bwd_lazy": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -114,6 +115,12 @@ class PackJob(C.Structure):
     _fields_ = [("w", _vp), ("out_fwd", _vp), ("out_t", _vp), ("total_fwd", _i64), ("total_t", _i64),
                 ("Cw_out", _i), ("Cw_in", _i), ("cpg_fwd", _i), ("nt_fwd", _i), ("cpg_t", _i), ("nt_t", _i),
                 ("first_block", _i), ("n_blocks", _i)]
+
+
+class ComposeJob(C.Structure):
+    """mis_compose_job of include/misamd.h."""
+    _fields_ = [("P", _vp), ("D", _vp), ("bd", _vp), ("bp", _vp), ("W", _vp), ("b", _vp),
+                ("Cout", _i), ("Cin", _i), ("first_block", _i), ("n_blocks", _i)]
 
 
 _lib = None

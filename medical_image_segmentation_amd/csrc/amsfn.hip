@@ -544,6 +544,26 @@ __global__ __launch_bounds__(TPB) void dw_compose_fwd_kernel(const float* __rest
   }
 }
 
+// the same composition for many layers: job j owns workgroups [first_block, first_block + n_blocks)
+__global__ __launch_bounds__(TPB) void dw_compose_multi_kernel(const mis_compose_job* __restrict__ jobs, int n_jobs) {
+  int j = 0;
+  while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].first_block) j++;
+  const mis_compose_job jb = jobs[j];
+  const int Cin = jb.Cin, Cout = jb.Cout, nW = Cout * Cin * 9;
+  const int total = nW + (jb.D ? Cout : 0);
+  for (int e = ((int)blockIdx.x - jb.first_block) * TPB + threadIdx.x; e < total; e += jb.n_blocks * TPB) {
+    if (e < nW) {
+      const int t = e % 9, i = (e / 9) % Cin, o = e / (9 * Cin);
+      jb.W[e] = jb.D ? jb.P[o * Cin + i] * jb.D[i * 9 + t] : (t == 4 ? jb.P[o * Cin + i] : 0.f);
+    } else {
+      const int o = e - nW;
+      float acc = 0.f;
+      for (int i = 0; i < Cin; i++) acc += jb.P[o * Cin + i] * jb.bd[i];
+      jb.b[o] = jb.bp[o] + acc;
+    }
+  }
+}
+
 // dP[o][i] = sum_t dW[o][i][t] D[i][t] + db[o] bd[i];  dD[i][t] = sum_o dW[o][i][t] P[o][i];
 // dbd[i] = sum_o db[o] P[o][i]   (dbp = db).  Fixed summation order.
 __global__ __launch_bounds__(TPB) void dw_compose_bwd_kernel(const float* __restrict__ P, const float* __restrict__ D,
@@ -980,6 +1000,13 @@ int mis_dwconv_compose_fwd(const float* P, const float* D, const float* bd, cons
   dw_compose_fwd_kernel<<<ew_grid((int64_t)Cout * Cin * 9 + Cout, TPB), TPB, 0, (hipStream_t)stream>>>(P, D, bd, bp, Cout,
                                                                                                      Cin, W, b);
   MIS_CHECK_LAUNCH("dw_compose_fwd_kernel");
+  return MIS_OK;
+}
+
+int mis_dwconv_compose_multi(const mis_compose_job* jobs, int n_jobs, int total_blocks, mis_stream_t stream) {
+  MIS_REQUIRE(jobs && n_jobs >= 1 && total_blocks >= n_jobs, "dwconv_compose_multi: bad arguments");
+  dw_compose_multi_kernel<<<total_blocks, TPB, 0, (hipStream_t)stream>>>(jobs, n_jobs);
+  MIS_CHECK_LAUNCH("dw_compose_multi_kernel");
   return MIS_OK;
 }
 

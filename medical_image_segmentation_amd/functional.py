@@ -208,9 +208,11 @@ class WeightPacker:
     inference nothing is packed after the first call.  The images live in persistent buffers and
     are handed to `ConvBnReluFn` through `packed_for`."""
 
-    def __init__(self, weights, dtype):
+    def __init__(self, weights, dtype, by_ptr=()):
+        """by_ptr: those of `weights` that reach the convs as aliases (see _PACKED_PTR)."""
         from . import _lib
         self.weights = [w for w in weights]
+        self.by_ptr = {id(w) for w in by_ptr}
         self.dtype = dtype
         self.epoch = _lib.PATH_EPOCH
         self.versions = None
@@ -252,14 +254,20 @@ class WeightPacker:
              _DT[self.dtype], _stream())
         self.versions = versions
         for w, wf, wt in self.images.values():
-            key = (id(w), self.dtype)
-            _PACKED[key] = (weakref.ref(w, lambda _r, k=key: _PACKED.pop(k, None)), w.data_ptr(), w._version, wf, wt,
-                            self.epoch)
+            table = _PACKED_PTR if id(w) in self.by_ptr else _PACKED
+            key = (w.data_ptr() if id(w) in self.by_ptr else id(w), self.dtype)
+            table[key] = (weakref.ref(w, lambda _r, k=key, t=table: t.pop(k, None)), w.data_ptr(), w._version, wf, wt,
+                          self.epoch)
 
 
 # (id(weight), dtype) -> (weak reference, data pointer, version, forward image, transposed image,
 # path epoch); an entry is used only for the very same tensor object, unchanged since it was packed
 _PACKED = {}
+
+
+# (data pointer, dtype) -> the same record, for the persistent buffers of a ComposedWeights plan: the convs receive
+# ALIASES of those buffers (a fresh tensor object per step, sharing memory and version counter with the buffer)
+_PACKED_PTR = {}
 
 
 def packed_for(weight, dtype):
@@ -269,7 +277,118 @@ def packed_for(weight, dtype):
     if (hit is not None and hit[0]() is weight and hit[1] == weight.data_ptr() and hit[2] == weight._version
             and hit[5] == _lib.PATH_EPOCH):
         return hit[3], hit[4]
+    hit = _PACKED_PTR.get((weight.data_ptr(), dtype))
+    if hit is not None:
+        base = hit[0]()
+        if (base is not None and base.shape == weight.shape and base.data_ptr() == weight.data_ptr()
+                and hit[2] == weight._version == base._version and hit[5] == _lib.PATH_EPOCH):
+            return hit[3], hit[4]
     return None
+
+
+# pconv.weight / 1x1 weight data pointer -> (weak reference to the plan, parameter versions, W buffer, b buffer or None)
+_COMPOSED = {}
+BATCH_WEIGHT_PREP = True     # (module attribute: the tests compare with the per-layer launches)
+
+
+class ComposedWeights:
+    """The dense 3x3 weights of every DWConv (W = P*D, b = bp + P bd; modules.py:52-60) and of every 1x1 conv that
+    runs on the 3x3 kernels (P at the centre tap), composed by ONE launch whenever a parameter changed, into
+    persistent float32 buffers; their operand images — and those of the plain 3x3 convs given in `leaves` — come
+    from one more launch (WeightPacker).  DwComposeFn / PointwisePadFn return aliases of the buffers when the
+    parameters still have the versions the buffers were composed from, else they compute per layer as before.
+    dw: [(dconv, pconv)] nn.Conv2d pairs; pw: [1x1 nn.Conv2d]; leaves: [3x3 nn.Conv2d]."""
+
+    def __init__(self, dw, pw, leaves, dtype):
+        from . import _lib
+        self.dtype, self.epoch = dtype, _lib.PATH_EPOCH
+        self.dw, self.pw, self.leaves = list(dw), list(pw), list(leaves)
+        self.params = self._params()
+        dev = self.params[0].device
+        self.entries = []            # (key pointer, parameter tuple, W, b)
+        jobs, first = [], 0
+        for dconv, pconv in self.dw:
+            Co, Ci = pconv.weight.shape[0], pconv.weight.shape[1]
+            W = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=dev)
+            b = torch.empty(Co, dtype=torch.float32, device=dev)
+            nb = max(1, min(64, (Co * Ci * 9 + Co + 255) // 256))
+            jobs.append(_lib.ComposeJob(pconv.weight.data_ptr(), dconv.weight.data_ptr(), dconv.bias.data_ptr(),
+                                        pconv.bias.data_ptr(), W.data_ptr(), b.data_ptr(), Co, Ci, first, nb))
+            first += nb
+            self.entries.append((pconv.weight.data_ptr(), (pconv.weight, dconv.weight, dconv.bias, pconv.bias), W, b))
+        for conv in self.pw:
+            Co, Ci = conv.weight.shape[0], conv.weight.shape[1]
+            W = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=dev)
+            nb = max(1, min(64, (Co * Ci * 9 + 255) // 256))
+            jobs.append(_lib.ComposeJob(conv.weight.data_ptr(), None, None, None, W.data_ptr(), None, Co, Ci, first, nb))
+            first += nb
+            self.entries.append((conv.weight.data_ptr(), (conv.weight,), W, None))
+        self.n_jobs, self.total_blocks = len(jobs), first
+        self.table = None
+        if jobs:
+            raw = b"".join(bytes(j) for j in jobs)
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        bufs = [e[2] for e in self.entries]
+        self.packer = WeightPacker(bufs + [c.weight for c in self.leaves], dtype, by_ptr=bufs)
+        self.versions = None
+
+    def _params(self):
+        ps = []
+        for dconv, pconv in self.dw:
+            ps += [pconv.weight, dconv.weight, dconv.bias, pconv.bias]
+        return ps + [c.weight for c in self.pw] + [c.weight for c in self.leaves]
+
+    def valid_for(self, dtype):
+        from . import _lib
+        now = self._params()
+        return (self.dtype == dtype and self.epoch == _lib.PATH_EPOCH and len(now) == len(self.params)
+                and all(a is b for a, b in zip(now, self.params))
+                and all(k == ps[0].data_ptr() for k, ps, _, _ in self.entries))
+
+    def refresh(self):
+        versions = [p._version for p in self.params]
+        if versions == self.versions:
+            return
+        if self.table is not None:
+            call("mis_dwconv_compose_multi", self.table.data_ptr(), self.n_jobs, self.total_blocks, _stream())
+            torch._C._increment_version([e[2] for e in self.entries])
+        self.packer.refresh()
+        self.versions = versions
+        ref = weakref.ref(self)
+        for key, ps, W, b in self.entries:
+            _COMPOSED[key] = (ref, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), W, b)
+
+
+def _composed_for(*params):
+    """(W, b) aliases from a live plan whose buffers were composed from exactly these parameter versions, else None."""
+    if not BATCH_WEIGHT_PREP:
+        return None
+    hit = _COMPOSED.get(params[0].data_ptr())
+    if hit is None or hit[0]() is None:
+        return None
+    _, versions, ptrs, W, b = hit
+    if versions != tuple(p._version for p in params) or ptrs != tuple(p.data_ptr() for p in params):
+        return None
+    return W.view_as(W), (b.view_as(b) if b is not None else None)
+
+
+def prepare_weights(model, dtype, dw, pw, leaves):
+    """Called at the top of a model's forward: composes / packs all conv weights in two launches (only when a
+    parameter changed since the last call).  The plan is kept on the module."""
+    if not BATCH_WEIGHT_PREP:
+        return
+    plan = model.__dict__.get("_mis_weight_plan")
+    if plan is None or not plan.valid_for(dtype):
+        dwl, pwl, lv = dw(), pw(), leaves()
+        ok = lambda t: t is not None and t.is_cuda and t.dtype == torch.float32
+        dwl = [(d, p) for d, p in dwl if ok(d.weight) and ok(p.weight) and ok(d.bias) and ok(p.bias)]
+        pwl = [c for c in pwl if ok(c.weight)]
+        lv = [c for c in lv if ok(c.weight)]
+        if not (dwl or pwl or lv):
+            return
+        plan = ComposedWeights(dwl, pwl, lv, dtype)
+        model.__dict__["_mis_weight_plan"] = plan
+    plan.refresh()
 
 
 def align_up(n, a):
@@ -1084,9 +1203,25 @@ def conv_bn_relu_w(x, x_ss, weight, bias, bn, training, link=None, pointwise=Fal
                               True, 0 if pointwise else 1, None, link)
 
 
+class PointwisePadFn(torch.autograd.Function):
+    """[Cout, Cin, 1, 1] -> the 3x3 weight with that matrix at the centre tap, taken from the model's
+    ComposedWeights plan (no launch here); the gradient is the centre tap of the 3x3 gradient."""
+
+    @staticmethod
+    def forward(ctx, weight, W):
+        return W.view_as(W)
+
+    @staticmethod
+    def backward(ctx, dW):
+        return (dW[:, :, 1:2, 1:2].contiguous() if dW is not None else None), None
+
+
 def pointwise_as_3x3(weight):
     """A 1x1 conv weight [Cout, Cin, 1, 1] as the 3x3 weight whose only non-zero tap is the centre:
     the 1x1 conv runs on the matrix-core 3x3 kernels (same sums, in the same order per tap)."""
+    hit = _composed_for(weight) if (weight.is_cuda and weight.dtype == torch.float32) else None
+    if hit is not None:
+        return PointwisePadFn.apply(weight, hit[0])
     return torch.nn.functional.pad(weight, (1, 1, 1, 1))
 
 
@@ -1099,10 +1234,14 @@ class DwComposeFn(torch.autograd.Function):
         Cout, Cin = P.shape[0], P.shape[1]
         Pc, Dc = P.detach().reshape(Cout, Cin).contiguous(), D.detach().reshape(Cin, 9).contiguous()
         bdc, bpc = bd.detach().contiguous(), bp.detach().contiguous()
-        W = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=P.device)
-        b = torch.empty(Cout, dtype=torch.float32, device=P.device)
-        call("mis_dwconv_compose_fwd", Pc.data_ptr(), Dc.data_ptr(), bdc.data_ptr(), bpc.data_ptr(), Cout, Cin,
-             W.data_ptr(), b.data_ptr(), _stream())
+        hit = _composed_for(P, D, bd, bp)
+        if hit is not None:                  # composed with every other layer's, at the top of the model's forward
+            W, b = hit
+        else:
+            W = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=P.device)
+            b = torch.empty(Cout, dtype=torch.float32, device=P.device)
+            call("mis_dwconv_compose_fwd", Pc.data_ptr(), Dc.data_ptr(), bdc.data_ptr(), bpc.data_ptr(), Cout, Cin,
+                 W.data_ptr(), b.data_ptr(), _stream())
         ctx.save_for_backward(Pc, Dc, bdc)
         ctx.shapes = (P.shape, D.shape)
         return W, b

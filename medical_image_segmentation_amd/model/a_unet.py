@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from .. import functional as F_
 from .unet import UNet
-from .utils.modules import AMSFN, DoubleConv
+from .utils.modules import AMSFN, DoubleConv, prepare_conv_weights
 
 
 class A_UNet(nn.Module):
@@ -63,6 +63,7 @@ class A_UNet(nn.Module):
             raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
         pool, noise, up = F_.MaxPool2x2Fn.apply, F_.dropout2d_noise, UNet._up
         x = F_.to_act(x, self._dtype())
+        prepare_conv_weights(self, x.dtype)
         # an encoder output is read by the four branches of its AMSFN block and by the decoder's skip connection:
         # five aliases whose gradients meet in one kernel (which also emits the encoder layer's BatchNorm-backward sums)
         def block(acpn, e):

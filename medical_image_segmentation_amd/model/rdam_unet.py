@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import functional as F_
 from .utils.attention import MDAM
-from .utils.modules import AMSFN, DoubleConv, ResDConv
+from .utils.modules import AMSFN, DoubleConv, ResDConv, prepare_conv_weights
 
 
 class RDAM_UNet(nn.Module):
@@ -77,6 +77,7 @@ class RDAM_UNet(nn.Module):
             raise ValueError(f"H and W must be multiples of 16 (four 2x2 poolings), got {tuple(x.shape[2:])}")
         pool, noise = F_.MaxPool2x2Fn.apply, F_.dropout2d_noise
         x = F_.to_act(x, self._dtype())
+        prepare_conv_weights(self, x.dtype)
         e1 = F_.Conv3x3Fn.apply(x, None, None, None, self.encoder1.weight, self.encoder1.bias)
         a = self.acpn0.forward_lazy(e1)
         m1 = self.att1(e1)

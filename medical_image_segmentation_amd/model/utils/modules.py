@@ -138,6 +138,26 @@ class AMSFN(nn.Module):
         _init_like_reference(self)
 
 
+def prepare_conv_weights(model, dtype):
+    """Top of a model's forward: every DWConv composition, every 1x1-as-3x3 weight and every operand image of
+    the model's 3x3 convs in two launches (functional.ComposedWeights), instead of one or two small launches per
+    layer and step.  Bare nn.Conv2d children of the model itself (RDAM_UNet.encoder1 / decoder4) count as 3x3 convs."""
+    def mods(kind):
+        return [m for m in model.modules() if isinstance(m, kind)]
+
+    def leaves():
+        out = [blk[0] for m in mods(DoubleConv) for blk in (m.cbr1, m.cbr2)]
+        out += [blk[0] for m in mods(ResDConv) for blk in (m.cbr1, m.cbr2, m.cbr3)]
+        out += [c for c in model.children() if isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3)]
+        return out
+
+    F_.prepare_weights(model, dtype,
+                       dw=lambda: [(m.dconv, m.pconv) for m in mods(DWConv)],
+                       pw=lambda: [c for m in mods(AMSFN) for c in (m.conv1x1[1], m.final_conv[0])]
+                                  + [m.c1[0] for m in mods(ResDConv)],
+                       leaves=leaves)
+
+
 class ResDConv(nn.Module):
     """Residual block of RDAM_UNet (modules.py:426-453): three chained 3x3 convs with dilations 1, 2, 3
     (each + BN, the first two + ReLU) plus a 1x1 conv + BN shortcut; out = relu(main + shortcut).

@@ -250,3 +250,54 @@ def test_attention_variants_full_size_step_properties(which):
     f = run(torch.float32, steps=3)
     assert abs(a[1] - f[0][1]) < 2e-2
     assert f[2][1] < f[0][1]
+
+
+@pytest.mark.parametrize("which", ["a_unet", "rdam_unet"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_weight_preparation_equals_per_layer(which, dtype):
+    """All DWConv compositions, 1x1-as-3x3 weights and operand images prepared by two launches at the top of the
+    forward (functional.ComposedWeights) against one or two launches per layer: three optimizer steps from the same
+    start give bit-identical losses, gradients and parameters (the expressions are the same; the plan must notice
+    every parameter update)."""
+    from medical_image_segmentation_amd import functional as F_
+    from medical_image_segmentation_amd.model.a_unet import A_UNet
+    from medical_image_segmentation_amd.model.rdam_unet import RDAM_UNet
+    from medical_image_segmentation_amd.utils.loss_fn import diceloss
+    from medical_image_segmentation_amd.utils.optim import clip_and_step
+    net = A_UNet if which == "a_unet" else RDAM_UNet
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 32, 48, device=DEV)
+    y = torch.randint(0, 4, (2, 32, 48), device=DEV)
+    out = {}
+    for batched in (True, False):
+        F_.BATCH_WEIGHT_PREP = batched
+        torch.manual_seed(11)
+        m = net(3, 4, 0, base_channels=32, compute_dtype=dtype).to(DEV).train()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-2)
+        params = list(m.parameters())
+        losses, calls = [], []
+        orig = F_.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+
+        F_.call = spy
+        try:
+            for _ in range(3):
+                opt.zero_grad()
+                loss = diceloss(["a", "b", "c"])(m(x), y)["total_loss"]
+                loss.backward()
+                losses.append(float(loss.detach()))
+                clip_and_step(opt, params, 1.0)
+        finally:
+            F_.call = orig
+        assert ("mis_dwconv_compose_multi" in calls) == batched
+        assert (calls.count("mis_dwconv_compose_fwd") == 0) == batched
+        out[batched] = (losses, [p.detach().clone() for p in params], [p.grad.clone() for p in params])
+    F_.BATCH_WEIGHT_PREP = True
+    assert out[True][0] == out[False][0]
+    for a, b in zip(out[True][1], out[False][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(out[True][2], out[False][2]):
+        assert torch.equal(a, b)
