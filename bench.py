@@ -71,8 +71,8 @@ PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node (default: WORLD_SIZE when a launcher set it, else 1)")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)      # (the first step after the barrier is issue-bound: ~2 ms once)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])

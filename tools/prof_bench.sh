@@ -5,7 +5,7 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/prof -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/prof -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > $OUT/bench.json 2> $OUT/bench.err
 echo "rc=$?"
 python3 - <<PY
 import csv,re
