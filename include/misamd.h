@@ -277,11 +277,11 @@ int mis_wgrad_reduce_multi(const mis_wgrad_reduce_job* jobs, int n_jobs, mis_str
 /* — ResDConv.cbr2 / cbr3, model/utils/modules.py:440-445 (d = 1 is the plain conv).  The data  */
 /* gradient of a dilated conv is mis_conv3x3_dilated_fwd on the transposed weight image with    */
 /* the same d.  Matrix-core kernels only (no vector-ALU fallback): *_supported tells.           */
-/* d = 0 (forward / data gradient only): the caller states that only the CENTRE tap of the     */
-/* packed 3x3 weights is non-zero — a 1x1 conv carried as a 3x3 (AMSFN's conv1x1 / final_conv,  */
-/* modules.py:801,838; ResDConv.c1, modules.py:432): the kernel then reads no halo and          */
-/* multiplies one tap instead of nine (same result).  The weight gradient of such a layer is    */
-/* the plain d = 1 one (its centre tap is the 1x1 gradient).                                    */
+/* d = 0: the caller states that only the CENTRE tap of the packed 3x3 weights is non-zero — a */
+/* 1x1 conv carried as a 3x3 (AMSFN's conv1x1 / final_conv, modules.py:801,838; ResDConv.c1,    */
+/* modules.py:432): the kernels then read no halo and multiply one tap instead of nine (same    */
+/* result); the weight gradient (also mis_conv3x3_wgrad_slabs with dilation 0) returns the      */
+/* centre tap — the 1x1 gradient — and ZEROS in the other eight.                                */
 int mis_conv3x3_dilated_supported(int dtype, int B, int H, int W, int Cin, int Cout, int dilation);
 int mis_conv3x3_dilated_stats_rows(int dtype, int B, int H, int W, int Cin, int Cout, int dilation);
 int mis_conv3x3_dilated_fwd(const void* x, const float* x_affine, const void* w_packed, const float* bias, int dtype,

@@ -161,7 +161,7 @@ int mis_conv3x3_wgrad(const void* x, const float* x_affine, const void* dz, int 
 
 int mis_conv3x3_wgrad_slabs_supported(int dtype, int B, int H, int W, int Ca, int Cb, int Cout, int dilation) {
   if (B < 1 || H < 1 || W < 1 || Ca < 1 || Cb < 0 || Cout < 1 || (dtype != MIS_F32 && dtype != MIS_BF16)) return 0;
-  if (dilation < 1 || dilation > 3 || (Cb > 0 && dilation != 1) || force_direct()) return 0;
+  if (dilation < 0 || dilation > 3 || (Cb > 0 && dilation != 1) || force_direct()) return 0;
   return (Cb > 0 ? conv3x3_wgrad_mfma_cat_supported(dtype, B, H, W, Ca, Cb, Cout)
                  : conv3x3_wgrad_mfma_supported(dtype, B, H, W, Ca, Cout)) ? 1 : 0;
 }
@@ -230,7 +230,7 @@ int mis_conv3x3_dilated_wgrad(const void* x, const float* x_affine, const void* 
   MIS_REQUIRE(x && dz && dw && workspace, "conv3x3_dilated_wgrad: null pointer");
   MIS_REQUIRE(!dbias || (bias_rows && n_bias_rows >= 1), "conv3x3_dilated_wgrad: dbias needs its partial rows");
   MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "conv3x3_dilated_wgrad: bad dtype %d", dtype);
-  if (dilation < 1 || dilation > 3 || force_direct() || !conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout)) {
+  if (dilation < 0 || dilation > 3 || force_direct() || !conv3x3_wgrad_mfma_supported(dtype, B, H, W, Cin, Cout)) {
     mis_set_error("conv3x3_dilated_wgrad: %d -> %d channels with dilation %d is not taken by the matrix-core kernels",
                   Cin, Cout, dilation);
     return MIS_ERR_UNSUPPORTED;

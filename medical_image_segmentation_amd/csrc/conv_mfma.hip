@@ -1255,6 +1255,9 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK + (WS ? WG_PRODUCERS : 0), (WS 
   constexpr int STHR = WS ? WG_PRODUCERS : NTHR;       // staging threads
   constexpr int G = Mf<T>::G;
   constexpr int TH = wg_tile_h<T>(WS, WCO * MTO * 16, WCI * NTI * 16);
+  // DIL == 0: the layer is a 1x1 conv carried as a 3x3 — only the centre tap of its gradient is wanted: no halo, one
+  // tap multiplied (the other eight accumulators stay zero and are written as zeros, so the reduction is unchanged)
+  constexpr int WT0 = DIL == 0 ? 4 : 0, WT1 = DIL == 0 ? 5 : 9;
   constexpr int HWW = WG_TW + 2 * DIL;           // halo width (34 without dilation)
   constexpr int PH = (TH + 2 * DIL) * HWW;       // halo positions
   constexpr int PZ = TH * WG_TW;                 // dz positions
@@ -1432,7 +1435,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK + (WS ? WG_PRODUCERS : 0), (WS 
     _Pragma("unroll") \
         for (int mo = 0; mo < MTO; mo++) a[mo] = tr_frag<RSZ>(zt, offz, r * WG_TW * RSZ + mo * 32); \
     _Pragma("unroll") \
-        for (int t = 0; t < 9; t++) { \
+        for (int t = WT0; t < WT1; t++) { \
     _Pragma("unroll") \
           for (int ni = 0; ni < NTI; ni++) { \
             const bf16x8 bq = tr_frag<RSX>(xh, offx, (r * HWW + ((t / 3) * HWW + (t % 3)) * DIL) * RSX + ni * 32); \
@@ -1452,7 +1455,7 @@ __global__ __launch_bounds__(64 * WCO * WCI * WK + (WS ? WG_PRODUCERS : 0), (WS 
             a[mo] = *reinterpret_cast<const float*>(zt + pos * RSZ + c * 4); \
           } \
     _Pragma("unroll") \
-          for (int t = 0; t < 9; t++) { \
+          for (int t = WT0; t < WT1; t++) { \
     _Pragma("unroll") \
             for (int ni = 0; ni < NTI; ni++) { \
               const int pos = (r + (t / 3) * DIL) * HWW + (t % 3) * DIL + px, c = (wci * NTI + ni) * 16 + (lane & 15); \
@@ -1727,8 +1730,8 @@ int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, f
               void* workspace, hipStream_t st, int dil, int* n_slabs_out = nullptr) {
   WgPlan p;
   const int Cin = in.channels();
-  if (dil < 1 || dil > 3) {
-    mis_set_error("conv3x3_wgrad_mfma: dilation %d not supported (1..3)", dil);
+  if (dil < 0 || dil > 3) {
+    mis_set_error("conv3x3_wgrad_mfma: dilation %d not supported (0..3)", dil);
     return MIS_ERR_UNSUPPORTED;
   }
   if (!plan_wgrad<T>(B, H, W, Cin, Cout, p, in.Ca, dil)) {
@@ -1742,6 +1745,7 @@ int run_wgrad(const ConvIn& in, const void* dz, int B, int H, int W, int Cout, f
   {                                                                                                        \
     auto kfn = dil == 2 ? conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK, 2>                          \
                : dil == 3 ? conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK, 3>                        \
+               : dil == 0 ? conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK, 0>                        \
                           : conv3x3_wgrad_mfma_kernel<T, MTO, NTI, WCO, WCI, WK, 1>;                       \
     if (p.lds > 48 * 1024)                                                                                 \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds); \
@@ -1801,7 +1805,7 @@ bool conv3x3_wgrad_mfma_supported(int dtype, int B, int H, int W, int Cin, int C
 // wave-specialised and may split K further than the plain one.
 size_t conv3x3_wgrad_mfma_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout) {
   int nsplit = 0;
-  for (int dil = 1; dil <= 3; dil++) {
+  for (int dil = 0; dil <= 3; dil++) {
     WgPlan p;
     const bool ok = dtype == MIS_BF16 ? plan_wgrad<bf16>(B, H, W, Cin, Cout, p, -1, dil)
                                       : plan_wgrad<float>(B, H, W, Cin, Cout, p, -1, dil);

@@ -968,7 +968,7 @@ class ConvBnReluFn(torch.autograd.Function):
 
         # weight gradient first, data gradient last: what consumes the data gradient runs right behind it
         dw = None
-        wdil = max(dil, 1)          # (a centre-tap layer's weight gradient is the plain 3x3 one)
+        wdil = dil                  # (0: only the centre tap of the weight gradient is computed, the others are zeros)
         if rows is not None:
             dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=wdil,
                                           defer=(ctx.bias_ref is not None and ctx.bias_ref() is not None

@@ -130,9 +130,10 @@ def test_dwconv_composition_matches_autograd(Cout, Cin):
 @pytest.mark.parametrize("lazy", [False, True])
 def test_pointwise_conv_multiplies_centre_tap_only(dtype, shape, lazy):
     """A 1x1 conv carried by the 3x3 kernels (AMSFN.conv1x1 / final_conv, modules.py:801,838): with
-    CENTER_TAP_CONVS the forward and the data gradient stage no halo and multiply one tap; the other eight
-    contribute exact zeros in the full form, so outputs, statistics and gradients are identical (shapes whose K
-    steps span several taps — 16 input channels in bfloat16 — run the full form either way)."""
+    CENTER_TAP_CONVS the forward, the data gradient and the weight gradient stage no halo and multiply one tap;
+    the other eight contribute exact zeros in the full form, so outputs, statistics and data gradients are
+    identical and the weight gradient agrees to float32 round-off (shapes whose K steps span several taps — 16
+    input channels in bfloat16 — run the full forward either way)."""
     from medical_image_segmentation_amd import functional as F_
     B, Ci, Co, H, W = shape
     g = torch.Generator().manual_seed(Ci * 1000 + Co)
@@ -153,7 +154,10 @@ def test_pointwise_conv_multiplies_centre_tap_only(dtype, shape, lazy):
                     bn.running_var.clone()))
     F_.CENTER_TAP_CONVS = True
     for a, b, what in zip(res[0], res[1], ("z", "affine", "dx", "dw", "dgamma", "running_var")):
-        assert torch.equal(a, b), what
+        if what == "dw":          # (the centre-tap weight gradient may split the pixel sum differently: float32 round-off)
+            assert rel_err(a, b) < 1e-5, what
+        else:
+            assert torch.equal(a, b), what
     # and against torch's own 1x1 conv + BatchNorm (float32 only: a plain numerical check of the embedding)
     if dtype == torch.float32:
         xr = x0.clone().requires_grad_(True)
