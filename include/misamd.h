@@ -483,6 +483,21 @@ typedef struct {
   int Cout, Cin, first_block, n_blocks;
 } mis_compose_job;
 int mis_dwconv_compose_multi(const mis_compose_job* jobs, int n_jobs, int total_blocks, mis_stream_t stream);
+/* The chain rule of many layers in one launch per 24 jobs; `jobs` is a HOST array (it travels  */
+/* in the kernel arguments).  D == NULL: the 1x1 layer — dP is the centre tap of dW; the other  */
+/* pointers of such a job are ignored.  Same arithmetic as mis_dwconv_compose_bwd.              */
+typedef struct {
+  const float* P;
+  const float* D;
+  const float* bd;
+  const float* dW;    /* [Cout][Cin][3][3] */
+  const float* db;    /* [Cout] */
+  float* dP;          /* [Cout][Cin] */
+  float* dD;          /* [Cin][9] */
+  float* dbd;         /* [Cin] */
+  int Cout, Cin;
+} mis_compose_bwd_job;
+int mis_dwconv_compose_bwd_multi(const mis_compose_bwd_job* jobs, int n_jobs, mis_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* RDAM_UNet (model/rdam_unet.py:7-115): what is not a convolution.              */

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mis_sum_gradients_workspace_bytes": (_sz, [_i]),
     "mis_sum_gradients": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_dwconv_compose_multi": (_i, [_vp, _i, _i, _vp]),
+    "mis_dwconv_compose_bwd_multi": (_i, [_vp, _i, _vp]),
     "mis_amsfn_workspace_bytes": (_sz, [_i, _i, _i]),
     "mis_amsfn_lazy_workspace_bytes": (_sz, [_i, _i, _i]),
     "mis_amsfn_fuse_bwd_lazy": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -121,6 +122,12 @@ class ComposeJob(C.Structure):
     """mis_compose_job of include/misamd.h."""
     _fields_ = [("P", _vp), ("D", _vp), ("bd", _vp), ("bp", _vp), ("W", _vp), ("b", _vp),
                 ("Cout", _i), ("Cin", _i), ("first_block", _i), ("n_blocks", _i)]
+
+
+class ComposeBwdJob(C.Structure):
+    """mis_compose_bwd_job of include/misamd.h."""
+    _fields_ = [("P", _vp), ("D", _vp), ("bd", _vp), ("dW", _vp), ("db", _vp), ("dP", _vp), ("dD", _vp), ("dbd", _vp),
+                ("Cout", _i), ("Cin", _i)]
 
 
 _lib = None

@@ -566,19 +566,18 @@ __global__ __launch_bounds__(TPB) void dw_compose_multi_kernel(const mis_compose
 
 // dP[o][i] = sum_t dW[o][i][t] D[i][t] + db[o] bd[i];  dD[i][t] = sum_o dW[o][i][t] P[o][i];
 // dbd[i] = sum_o db[o] P[o][i]   (dbp = db).  Fixed summation order.
-__global__ __launch_bounds__(TPB) void dw_compose_bwd_kernel(const float* __restrict__ P, const float* __restrict__ D,
-                                                             const float* __restrict__ bd,
-                                                             const float* __restrict__ dW,
-                                                             const float* __restrict__ db, int Cout, int Cin,
-                                                             float* __restrict__ dP, float* __restrict__ dD,
-                                                             float* __restrict__ dbd) {
+__device__ __forceinline__ void dw_compose_bwd_body(const float* __restrict__ P, const float* __restrict__ D,
+                                                    const float* __restrict__ bd, const float* __restrict__ dW,
+                                                    const float* __restrict__ db, int Cout, int Cin,
+                                                    float* __restrict__ dP, float* __restrict__ dD,
+                                                    float* __restrict__ dbd, int blk, int nblk) {
   // dP: one thread per element (9 terms).  dD and dbd sum over Cout: 8 consecutive lanes share an
   // element (lane j takes o = j, j+8, ...) and are summed on the DPP path, so the dependent chain is
   // Cout/8 long instead of Cout.  TPB is a multiple of 8 and the grid-stride keeps lane groups whole.
   // (the 8-lane groups start at a multiple of 8, so that a group is one aligned lane octet of a wave)
   const int nP = Cout * Cin, nP8 = (nP + 7) & ~7, nD = Cin * 9;
   const int total = nP8 + 8 * (nD + Cin);
-  for (int e = blockIdx.x * TPB + threadIdx.x; e < total; e += gridDim.x * TPB) {
+  for (int e = blk * TPB + threadIdx.x; e < total; e += nblk * TPB) {
     float acc = 0.f;
     if (e < nP) {
       const int i = e % Cin, o = e / Cin;
@@ -601,6 +600,36 @@ __global__ __launch_bounds__(TPB) void dw_compose_bwd_kernel(const float* __rest
         else dbd[g - nD] = acc;
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void dw_compose_bwd_kernel(const float* __restrict__ P, const float* __restrict__ D,
+                                                             const float* __restrict__ bd,
+                                                             const float* __restrict__ dW,
+                                                             const float* __restrict__ db, int Cout, int Cin,
+                                                             float* __restrict__ dP, float* __restrict__ dD,
+                                                             float* __restrict__ dbd) {
+  dw_compose_bwd_body(P, D, bd, dW, db, Cout, Cin, dP, dD, dbd, blockIdx.x, gridDim.x);
+}
+
+// The chain rule of MANY layers in one launch (the jobs travel in the kernel arguments): layer j owns workgroups
+// [first[j], first[j+1]).  D == NULL: a 1x1 conv carried as a 3x3 — dP is the centre tap of dW.
+constexpr int COMPOSE_BWD_MAX = 24;
+struct ComposeBwdArgs {
+  mis_compose_bwd_job job[COMPOSE_BWD_MAX];
+  int first[COMPOSE_BWD_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(TPB) void dw_compose_bwd_multi_kernel(const ComposeBwdArgs a) {
+  int j = 0;
+  while (j + 1 < a.n && (int)blockIdx.x >= a.first[j + 1]) j++;
+  const mis_compose_bwd_job& jb = a.job[j];
+  const int blk = (int)blockIdx.x - a.first[j], nblk = a.first[j + 1] - a.first[j];
+  if (jb.D) {
+    dw_compose_bwd_body(jb.P, jb.D, jb.bd, jb.dW, jb.db, jb.Cout, jb.Cin, jb.dP, jb.dD, jb.dbd, blk, nblk);
+  } else {
+    const int nP = jb.Cout * jb.Cin;
+    for (int e = blk * TPB + threadIdx.x; e < nP; e += nblk * TPB) jb.dP[e] = jb.dW[(int64_t)e * 9 + 4];
   }
 }
 
@@ -1007,6 +1036,33 @@ int mis_dwconv_compose_multi(const mis_compose_job* jobs, int n_jobs, int total_
   MIS_REQUIRE(jobs && n_jobs >= 1 && total_blocks >= n_jobs, "dwconv_compose_multi: bad arguments");
   dw_compose_multi_kernel<<<total_blocks, TPB, 0, (hipStream_t)stream>>>(jobs, n_jobs);
   MIS_CHECK_LAUNCH("dw_compose_multi_kernel");
+  return MIS_OK;
+}
+
+int mis_dwconv_compose_bwd_multi(const mis_compose_bwd_job* jobs, int n_jobs, mis_stream_t stream) {
+  MIS_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), "dwconv_compose_bwd_multi: null job array");
+  for (int j = 0; j < n_jobs; j++) {
+    const mis_compose_bwd_job& jb = jobs[j];
+    MIS_REQUIRE(jb.dW && jb.dP && jb.Cout >= 1 && jb.Cin >= 1 && (int64_t)jb.Cout * jb.Cin * 9 < (1 << 30),
+                "dwconv_compose_bwd_multi: bad job %d", j);
+    MIS_REQUIRE(!jb.D || (jb.P && jb.bd && jb.db && jb.dD && jb.dbd), "dwconv_compose_bwd_multi: job %d lacks a DWConv operand", j);
+  }
+  for (int j0 = 0; j0 < n_jobs; j0 += COMPOSE_BWD_MAX) {
+    ComposeBwdArgs a;
+    a.n = n_jobs - j0 < COMPOSE_BWD_MAX ? n_jobs - j0 : COMPOSE_BWD_MAX;
+    int total = 0;
+    for (int j = 0; j < a.n; j++) {
+      a.job[j] = jobs[j0 + j];
+      a.first[j] = total;
+      const int64_t work = a.job[j].D ? (int64_t)a.job[j].Cout * a.job[j].Cin + 8 + a.job[j].Cin * 80
+                                      : (int64_t)a.job[j].Cout * a.job[j].Cin;
+      int nb = (int)((work + TPB - 1) / TPB);
+      total += nb > 64 ? 64 : nb;
+    }
+    a.first[a.n] = total;
+    dw_compose_bwd_multi_kernel<<<total, TPB, 0, (hipStream_t)stream>>>(a);
+    MIS_CHECK_LAUNCH("dw_compose_bwd_multi_kernel");
+  }
   return MIS_OK;
 }
 

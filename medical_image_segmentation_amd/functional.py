@@ -288,6 +288,8 @@ def packed_for(weight, dtype):
 
 # pconv.weight / 1x1 weight data pointer -> (weak reference to the plan, parameter versions, W buffer, b buffer or None)
 _COMPOSED = {}
+_COMPOSED_W = {}             # data pointer of a plan's W buffer -> (weak reference to the plan, the parameters behind it)
+DEFER_COMPOSED = True        # (module attribute: the tests compare) gradients of composed weights wait for the end of the pass
 BATCH_WEIGHT_PREP = True     # (module attribute: the tests compare with the per-layer launches)
 
 
@@ -357,6 +359,7 @@ class ComposedWeights:
         ref = weakref.ref(self)
         for key, ps, W, b in self.entries:
             _COMPOSED[key] = (ref, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), W, b)
+            _COMPOSED_W[W.data_ptr()] = (ref, tuple(ps))
 
 
 def _composed_for(*params):
@@ -521,7 +524,8 @@ def flush_wgrad_reduces(on_second_stream=False):
     stream of the pass and must stay referenced until that stream has waited for the second one."""
     held = []
     while _wgrad_pending:
-        (dev, st), pending = _wgrad_pending.popitem()
+        key, pending = _wgrad_pending.popitem()
+        dev, st = key
         jobs = (_WgradJob * len(pending))()
         nbytes = 0
         main = None
@@ -544,7 +548,30 @@ def flush_wgrad_reduces(on_second_stream=False):
             if n_jobs:
                 with _prof("wgrad_reduce_multi", 0, nbytes):
                     call("mis_wgrad_reduce_multi", ctypes.addressof(jobs), n_jobs, st)
+            held.extend(_flush_compose_bwd(key, st, on_second_stream))
+    for key in list(_compose_bwd_pending):          # (none expected: their weight gradients were pending above)
+        with torch.cuda.device(key[0]):
+            held.extend(_flush_compose_bwd(key, key[1], False))
+    _pending_dw.clear()
     return held
+
+
+# Gradients of COMPOSED weights (ComposedWeights: W = P*D of a DWConv, a 1x1 weight at the centre tap): when the
+# weight gradient of such a layer is pending, the chain rule back to the parameters is pending with it — one launch
+# per 24 layers right behind the reductions, instead of one per layer inside the pass.
+_pending_dw = {}              # data pointer of a pending dw / dbias -> (device index, stream handle) of its reduction
+_compose_bwd_pending = {}     # (device index, stream handle) -> [(job fields, tensors kept alive)]
+
+
+def _flush_compose_bwd(key, st, keep):
+    pending = _compose_bwd_pending.pop(key, None)
+    if not pending:
+        return []
+    jobs = (_lib.ComposeBwdJob * len(pending))()
+    for j, (f, _) in zip(jobs, pending):
+        j.P, j.D, j.bd, j.dW, j.db, j.dP, j.dD, j.dbd, j.Cout, j.Cin = f
+    call("mis_dwconv_compose_bwd_multi", ctypes.addressof(jobs), len(pending), st)
+    return [pending] if keep else []
 
 
 def _in_backward_pass():
@@ -590,6 +617,9 @@ def _wgrad_deferred(x, dz, x_ss, x2, x2_ss, bias_rows, dilation, dw, Ca, Cb, Cou
         fields = None
     # The pending entry keeps the MEMORY of dw / dbias alive (their storages), not the tensors: autograd
     # takes a returned gradient as .grad without copying only while nobody else refers to the tensor.
+    _pending_dw[dw.data_ptr()] = (x.device.index, st)
+    if dbias is not None:
+        _pending_dw[dbias.data_ptr()] = (x.device.index, st)
     _wgrad_pending.setdefault((x.device.index, st), []).append(
         (fields,
          (slabs, dw.untyped_storage(), rows, dbias.untyped_storage() if dbias is not None else None) + extra))
@@ -632,7 +662,17 @@ def can_defer_wgrad(weight, bias=None):
     the pass then waits for the second stream) and this node computes its gradient at once."""
     global _deferred_pass
     mode = True
-    for t in (weight, bias):
+    tensors = (weight, bias)
+    if not weight.is_leaf:
+        # a composed weight (ComposedWeights): its gradient goes through DwComposeFn / PointwisePadFn to the
+        # parameters it was composed from — those decide; the slab launch stays on the stream of the pass (the
+        # networks that compose weights lose time on the second stream: A_UNet 31.96 vs 31.63 ms)
+        hit = _COMPOSED_W.get(weight.data_ptr()) if (DEFER_COMPOSED and BATCH_WEIGHT_PREP) else None
+        if hit is None or hit[0]() is None:
+            return False
+        tensors = hit[1] + ((bias,) if (bias is not None and bias.is_leaf) else ())
+        mode = DEFER_SAME_STREAM
+    for t in tensors:
         if t is None:
             continue
         if not t.is_leaf or t.grad is not None or t._backward_hooks:
@@ -642,6 +682,8 @@ def can_defer_wgrad(weight, bias=None):
                 return False
             if not DP_SIDE_STREAM:
                 mode = DEFER_SAME_STREAM
+    if not weight.is_leaf:
+        mode = DEFER_SAME_STREAM
     try:
         task = torch._C._current_graph_task_id()
     except AttributeError:
@@ -651,7 +693,7 @@ def can_defer_wgrad(weight, bias=None):
     if task != _deferred_pass:
         _deferred_pass = task
         _deferred_params.clear()
-    keys = [t.data_ptr() for t in (weight, bias) if t is not None]
+    keys = [t.data_ptr() for t in (weight,) + tuple(tensors) if t is not None]
     if any(k in _deferred_params for k in keys):
         flush_wgrad_reduces()
         return False
@@ -970,9 +1012,11 @@ class ConvBnReluFn(torch.autograd.Function):
         dw = None
         wdil = dil                  # (0: only the centre tap of the weight gradient is computed, the others are zeros)
         if rows is not None:
+            # (the bias of a composed weight is a per-step alias that may be gone by now: its parameters decide)
+            b_now = ctx.bias_ref() if ctx.bias_ref is not None else None
             dw, dbias = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, (rows, n_rows), dilation=wdil,
-                                          defer=(ctx.bias_ref is not None and ctx.bias_ref() is not None
-                                                 and can_defer_wgrad(weight, ctx.bias_ref())))
+                                          defer=((b_now is not None or not weight.is_leaf)
+                                                 and can_defer_wgrad(weight, b_now)))
         elif want_dw:
             dw = conv3x3_wgrad_raw(x, dz, x_ss, x2, x2_ss, dilation=wdil, defer=can_defer_wgrad(weight))
         data_gradient()
@@ -1213,7 +1257,16 @@ class PointwisePadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dW):
-        return (dW[:, :, 1:2, 1:2].contiguous() if dW is not None else None), None
+        if dW is None:
+            return None, None
+        key = _pending_dw.get(dW.data_ptr()) if dW.is_contiguous() else None
+        if key is None:
+            return dW[:, :, 1:2, 1:2].contiguous(), None
+        Cout, Cin = dW.shape[0], dW.shape[1]
+        dP = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=dW.device)
+        _compose_bwd_pending.setdefault(key, []).append(
+            ((None, None, None, dW.data_ptr(), None, dP.data_ptr(), None, None, Cout, Cin), (dW, dP.untyped_storage())))
+        return dP, None
 
 
 def pointwise_as_3x3(weight):
@@ -1256,8 +1309,18 @@ class DwComposeFn(torch.autograd.Function):
         dP = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
         dD = torch.empty((Cin, 9), dtype=torch.float32, device=dev)
         dbd = torch.empty(Cin, dtype=torch.float32, device=dev)
-        call("mis_dwconv_compose_bwd", Pc.data_ptr(), Dc.data_ptr(), bdc.data_ptr(), dW.data_ptr(), db.data_ptr(), Cout,
-             Cin, dP.data_ptr(), dD.data_ptr(), dbd.data_ptr(), _stream())
+        key = _pending_dw.get(dW.data_ptr())
+        if key is not None:                 # dW (and db) are complete only after the pending reductions: wait with them
+            _compose_bwd_pending.setdefault(key, []).append(
+                ((Pc.data_ptr(), Dc.data_ptr(), bdc.data_ptr(), dW.data_ptr(), db.data_ptr(), dP.data_ptr(),
+                  dD.data_ptr(), dbd.data_ptr(), Cout, Cin),
+                 # (storages, not tensors, of what autograd receives: it takes a gradient as .grad without a copy
+                 # only while nobody else refers to the tensor — and a copy made now would copy unwritten memory)
+                 (Pc, Dc, bdc, dW, db.untyped_storage(), dP.untyped_storage(), dD.untyped_storage(),
+                  dbd.untyped_storage())))
+        else:
+            call("mis_dwconv_compose_bwd", Pc.data_ptr(), Dc.data_ptr(), bdc.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                 Cout, Cin, dP.data_ptr(), dD.data_ptr(), dbd.data_ptr(), _stream())
         ps, ds = ctx.shapes
         return dP.reshape(ps), dD.reshape(ds), dbd, db
 

@@ -258,7 +258,8 @@ def test_batched_weight_preparation_equals_per_layer(which, dtype):
     """All DWConv compositions, 1x1-as-3x3 weights and operand images prepared by two launches at the top of the
     forward (functional.ComposedWeights) against one or two launches per layer: three optimizer steps from the same
     start give bit-identical losses, gradients and parameters (the expressions are the same; the plan must notice
-    every parameter update)."""
+    every parameter update) — with and without the deferral of the composed weights' gradients to the end of the
+    backward pass (functional.DEFER_COMPOSED)."""
     from medical_image_segmentation_amd import functional as F_
     from medical_image_segmentation_amd.model.a_unet import A_UNet
     from medical_image_segmentation_amd.model.rdam_unet import RDAM_UNet
@@ -269,8 +270,9 @@ def test_batched_weight_preparation_equals_per_layer(which, dtype):
     x = torch.randn(2, 3, 32, 48, device=DEV)
     y = torch.randint(0, 4, (2, 32, 48), device=DEV)
     out = {}
-    for batched in (True, False):
-        F_.BATCH_WEIGHT_PREP = batched
+    for batched in (True, "no deferral", False):
+        F_.BATCH_WEIGHT_PREP = bool(batched)
+        F_.DEFER_COMPOSED = batched is True
         torch.manual_seed(11)
         m = net(3, 4, 0, base_channels=32, compute_dtype=dtype).to(DEV).train()
         opt = torch.optim.AdamW(m.parameters(), lr=1e-2)
@@ -292,12 +294,16 @@ def test_batched_weight_preparation_equals_per_layer(which, dtype):
                 clip_and_step(opt, params, 1.0)
         finally:
             F_.call = orig
-        assert ("mis_dwconv_compose_multi" in calls) == batched
-        assert (calls.count("mis_dwconv_compose_fwd") == 0) == batched
+        assert ("mis_dwconv_compose_multi" in calls) == bool(batched)
+        assert (calls.count("mis_dwconv_compose_fwd") == 0) == bool(batched)
+        # the gradients of the composed weights wait for the end of the pass: one chain-rule launch per 24 layers
+        assert ("mis_dwconv_compose_bwd_multi" in calls) == (batched is True)
+        assert (calls.count("mis_dwconv_compose_bwd") == 0) == (batched is True)
         out[batched] = (losses, [p.detach().clone() for p in params], [p.grad.clone() for p in params])
-    F_.BATCH_WEIGHT_PREP = True
-    assert out[True][0] == out[False][0]
-    for a, b in zip(out[True][1], out[False][1]):
-        assert torch.equal(a, b)
-    for a, b in zip(out[True][2], out[False][2]):
-        assert torch.equal(a, b)
+    F_.BATCH_WEIGHT_PREP = F_.DEFER_COMPOSED = True
+    for other in ("no deferral", False):
+        assert out[True][0] == out[other][0]
+        for a, b in zip(out[True][1], out[other][1]):
+            assert torch.equal(a, b)
+        for a, b in zip(out[True][2], out[other][2]):
+            assert torch.equal(a, b)
