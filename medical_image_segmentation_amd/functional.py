@@ -286,9 +286,9 @@ def packed_for(weight, dtype):
     return None
 
 
-# pconv.weight / 1x1 weight data pointer -> (weak reference to the plan, parameter versions, W buffer, b buffer or None)
+# pconv.weight / 1x1 weight data pointer -> (weak reference to the plan, index of the layer in plan.entries)
 _COMPOSED = {}
-_COMPOSED_W = {}             # data pointer of a plan's W buffer -> (weak reference to the plan, the parameters behind it)
+_COMPOSED_W = {}             # data pointer of a plan's W buffer -> the same
 DEFER_COMPOSED = True        # (module attribute: the tests compare) gradients of composed weights wait for the end of the pass
 BATCH_WEIGHT_PREP = True     # (module attribute: the tests compare with the per-layer launches)
 
@@ -357,9 +357,19 @@ class ComposedWeights:
         self.packer.refresh()
         self.versions = versions
         ref = weakref.ref(self)
-        for key, ps, W, b in self.entries:
-            _COMPOSED[key] = (ref, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), W, b)
-            _COMPOSED_W[W.data_ptr()] = (ref, tuple(ps))
+        # (the registries hold the plan weakly and an index into it: a dead model's buffers and parameters go with it)
+        self.composed_from = [(tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps)) for _, ps, _, _ in self.entries]
+        for i, (key, ps, W, b) in enumerate(self.entries):
+            _COMPOSED[key] = (ref, i)
+            _COMPOSED_W[W.data_ptr()] = (ref, i)
+
+    def __del__(self):
+        entries = getattr(self, "entries", ())
+        for table, keys in ((_COMPOSED, [e[0] for e in entries]), (_COMPOSED_W, [e[2].data_ptr() for e in entries])):
+            for k in keys:
+                hit = table.get(k)
+                if hit is not None and hit[0]() in (None, self):
+                    table.pop(k, None)
 
 
 def _composed_for(*params):
@@ -367,11 +377,13 @@ def _composed_for(*params):
     if not BATCH_WEIGHT_PREP:
         return None
     hit = _COMPOSED.get(params[0].data_ptr())
-    if hit is None or hit[0]() is None:
+    plan = hit[0]() if hit is not None else None
+    if plan is None:
         return None
-    _, versions, ptrs, W, b = hit
+    versions, ptrs = plan.composed_from[hit[1]]
     if versions != tuple(p._version for p in params) or ptrs != tuple(p.data_ptr() for p in params):
         return None
+    _, _, W, b = plan.entries[hit[1]]
     return W.view_as(W), (b.view_as(b) if b is not None else None)
 
 
@@ -668,9 +680,10 @@ def can_defer_wgrad(weight, bias=None):
         # parameters it was composed from — those decide; the slab launch stays on the stream of the pass (the
         # networks that compose weights lose time on the second stream: A_UNet 31.96 vs 31.63 ms)
         hit = _COMPOSED_W.get(weight.data_ptr()) if (DEFER_COMPOSED and BATCH_WEIGHT_PREP) else None
-        if hit is None or hit[0]() is None:
+        plan = hit[0]() if hit is not None else None
+        if plan is None:
             return False
-        tensors = hit[1] + ((bias,) if (bias is not None and bias.is_leaf) else ())
+        tensors = tuple(plan.entries[hit[1]][1]) + ((bias,) if (bias is not None and bias.is_leaf) else ())
         mode = DEFER_SAME_STREAM
     for t in tensors:
         if t is None:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Counts the ATen ops one bench-style training step issues (besides the library's own kernels)
-and where they come from: finds stray fills/copies.  usage: python tools/trace_aten.py"""
+and where they come from: finds stray fills/copies.  usage: python tools/trace_aten.py [unet|a_unet|rdam_unet]"""
 import collections
 import os
 import sys
@@ -34,11 +34,20 @@ def main():
     from medical_image_segmentation_amd.utils.metrics import Metrics
     from medical_image_segmentation_amd.utils.optim import clip_and_step
     dev = torch.device("cuda:0")
-    model = UNet(1, 4, 0, base_channels=32, compute_dtype=torch.bfloat16).to(dev).train()
+    which = sys.argv[1] if len(sys.argv) > 1 else "unet"
+    if which == "unet":
+        model, cin = UNet(1, 4, 0, base_channels=32, compute_dtype=torch.bfloat16), 1
+    elif which == "a_unet":
+        from medical_image_segmentation_amd.model.a_unet import A_UNet
+        model, cin = A_UNet(3, 4, 0, base_channels=32, compute_dtype=torch.bfloat16), 3
+    else:
+        from medical_image_segmentation_amd.model.rdam_unet import RDAM_UNet
+        model, cin = RDAM_UNet(3, 4, 0, base_channels=32, compute_dtype=torch.bfloat16), 3
+    model = model.to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=8e-4, betas=(0.95, 0.999), weight_decay=1e-4)
     names = ["a", "b", "c"]
     loss_fn, metric = diceloss(names), Metrics(names)
-    x = torch.randn(16, 1, 512, 512, device=dev)
+    x = torch.randn(16, cin, 512, 512, device=dev)
     t = torch.randint(0, 4, (16, 512, 512), device=dev)
     params = list(model.parameters())
 
