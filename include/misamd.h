@@ -425,6 +425,10 @@ int mis_maxpool3x3s1_fwd(const void* x, const float* x_affine, int dtype, int B,
                          uint8_t* argmax, mis_stream_t stream);
 int mis_maxpool3x3s1_bwd(const void* dy, const uint8_t* argmax, int dtype, int B, int H, int W, int C, void* dx,
                          mis_stream_t stream);
+/* Test hook (process-global): 1 = every input goes through the generic row-strip kernels,  */
+/* 0 (default) = bf16 tensors of 8-channel vectors take the integer-key forward (lazy input)  */
+/* and the row-run backward.  Returns the previous setting.                                    */
+int mis_set_maxpool3_path(int strip_kernels);
 /* Fusion (modules.py:846-868): z / z_affine are HOST arrays of 4 device pointers  */
 /* (the branch outputs c1..c4, [B][HW][C] each, lazy when the affine is not NULL).  */
 /*   s[b][k*C+c] = mean_p act_k          (AdaptiveAvgPool2d(1) + cat)               */

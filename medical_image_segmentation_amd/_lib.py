@@ -91,6 +91,7 @@ PROTOTYPES = {
     "mis_nchw_f32_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mis_maxpool3x3s1_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mis_maxpool3x3s1_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mis_set_maxpool3_path": (_i, [_i]),
     "mis_sum_gradients_workspace_bytes": (_sz, [_i]),
     "mis_sum_gradients": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_dwconv_compose_multi": (_i, [_vp, _i, _i, _vp]),

@@ -27,6 +27,8 @@ constexpr int TPB = 256;
 // (MP3_R+2)*3/MP3_R loads and lazy-input conversions instead of 9.
 constexpr int MP3_R = 4;
 
+// Every load of a strip is unconditional (coordinates clamped into the image, the value masked afterwards): the
+// loop body is one basic block, so all (MP3_R+2)*3 loads are in flight together instead of one per branch.
 template <typename T, int V>
 __global__ __launch_bounds__(TPB) void maxpool3_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                            uint8_t* __restrict__ arg, int B, int H, int W, int C,
@@ -48,35 +50,35 @@ __global__ __launch_bounds__(TPB) void maxpool3_fwd_kernel(const T* __restrict__
     p /= (unsigned)W;
     const int y0 = (int)(p % HS) * MP3_R;
     const int b = (int)(p / HS);
+    const T* xb = x + (int64_t)b * H * W * C + cv * V;
+    const bool okx[3] = {xo > 0, true, xo + 1 < W};
+    const int xc[3] = {xo > 0 ? xo - 1 : 0, xo, xo + 1 < W ? xo + 1 : W - 1};
+    float v[MP3_R + 2][3][V];
+#pragma unroll
+    for (int r = 0; r < MP3_R + 2; r++) {
+      const int yy = y0 - 1 + r, yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
+      for (int d = 0; d < 3; d++) vload<T, V>(xb + ((int64_t)yc * W + xc[d]) * C, v[r][d]);
+    }
     float hm[3][V];          // per input row: maximum of its 3 taps ...
     int ha[3][V];            // ... and which tap (0..2) supplied it
     bool hv[3];              // row inside the image
 #pragma unroll
-    for (int q = 0; q < 3; q++)
-#pragma unroll
-      for (int k = 0; k < V; k++) { hm[q][k] = -INFINITY; ha[q][k] = 0; }
-#pragma unroll
     for (int r = 0; r < MP3_R + 2; r++) {
       const int s = r % 3, yy = y0 - 1 + r;
       hv[s] = yy >= 0 && yy < H;
-      if (hv[s]) {
-        // start below everything at the first tap inside the image: a later tap wins only if greater, or NaN
-        // over a number (`!(v <= m)` holds for both; `m == m` keeps the first NaN)
+      // start below everything at the first tap inside the image: a later tap wins only if greater, or NaN
+      // over a number (`!(v <= m)` holds for both; `m == m` keeps the first NaN); padding never wins
 #pragma unroll
-        for (int k = 0; k < V; k++) { hm[s][k] = -INFINITY; ha[s][k] = xo > 0 ? 0 : 1; }
+      for (int k = 0; k < V; k++) { hm[s][k] = -INFINITY; ha[s][k] = okx[0] ? 0 : 1; }
 #pragma unroll
-        for (int dx = -1; dx <= 1; dx++) {
-          const int xx = xo + dx;
-          if (xx < 0 || xx >= W) continue;                             // padding never wins
-          float v[V];
-          vload<T, V>(x + (((int64_t)b * H + yy) * W + xx) * C + cv * V, v);
-          affine_relu_rounded<T, V>(v, aff, C, cv * V);
+      for (int d = 0; d < 3; d++) {
+        affine_relu_rounded<T, V>(v[r][d], aff, C, cv * V);
 #pragma unroll
-          for (int k = 0; k < V; k++) {
-            const bool take = !(v[k] <= hm[s][k]) && (hm[s][k] == hm[s][k]);
-            hm[s][k] = take ? v[k] : hm[s][k];
-            ha[s][k] = take ? dx + 1 : ha[s][k];
-          }
+        for (int k = 0; k < V; k++) {
+          const bool take = okx[d] && !(v[r][d][k] <= hm[s][k]) && (hm[s][k] == hm[s][k]);
+          hm[s][k] = take ? v[r][d][k] : hm[s][k];
+          ha[s][k] = take ? d : ha[s][k];
         }
       }
       if (r < 2) continue;
@@ -93,10 +95,9 @@ __global__ __launch_bounds__(TPB) void maxpool3_fwd_kernel(const T* __restrict__
 #pragma unroll
       for (int d = 0; d < 3; d++) {
         const int q = (r - 2 + d) % 3;
-        if (!hv[q]) continue;
 #pragma unroll
         for (int k = 0; k < V; k++) {
-          const bool take = !(hm[q][k] <= m[k]) && (m[k] == m[k]);
+          const bool take = hv[q] && !(hm[q][k] <= m[k]) && (m[k] == m[k]);
           m[k] = take ? hm[q][k] : m[k];
           am[k] = take ? d * 3 + ha[q][k] : am[k];
         }
@@ -125,38 +126,316 @@ __global__ __launch_bounds__(TPB) void maxpool3_fwd_kernel(const T* __restrict__
   }
 }
 
+// The recorded positions of a vector as one load.
+template <int V>
+__device__ __forceinline__ void load_positions(const uint8_t* __restrict__ p, int (&a)[V]) {
+  if constexpr (V == 8) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      a[k] = (u.x >> (8 * k)) & 255;
+      a[4 + k] = (u.y >> (8 * k)) & 255;
+    }
+  } else if constexpr (V == 4) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = (u >> (8 * k)) & 255;
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; k++) a[k] = p[k];
+  }
+}
+
+// Backward as a gather over the same strips: a thread owns MP3_R rows of one column and channel vector and
+// reads the gradient and the recorded positions of the (MP3_R+2) x 3 windows that can point into the strip,
+// each once (3*(MP3_R+2)/MP3_R loads per output instead of 9), all unconditional.  The window centred at
+// (yq, xq) gives its gradient to pixel (yq + t - 1, xq + u - 1) when its recorded position is 3t + u.
 template <typename T, int V>
 __global__ __launch_bounds__(TPB) void maxpool3_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ arg,
                                                            T* __restrict__ dx, int B, int H, int W, int C) {
-  const int CV = C / V;
-  const int64_t total = (int64_t)B * H * W * CV;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
-    const int cv = (int)(i % CV);
-    int64_t p = i / CV;
-    const int xi = (int)(p % W);
-    p /= W;
-    const int yi = (int)(p % H);
-    const int b = (int)(p / H);
-    float acc[V];
+  const unsigned CV = (unsigned)(C / V), HS = (unsigned)((H + MP3_R - 1) / MP3_R);
+  const unsigned total = (unsigned)B * HS * (unsigned)W * CV;
+  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
+    const unsigned cv = i % CV;
+    unsigned p = i / CV;
+    const int xi = (int)(p % (unsigned)W);
+    p /= (unsigned)W;
+    const int y0 = (int)(p % HS) * MP3_R;
+    const int b = (int)(p / HS);
+    const int64_t base = (int64_t)b * H * W * C + cv * V;
+    // window column xq = xi - ox sees this column at u = ox + 1: d = 0, 1, 2 <-> ox = -1, 0, 1 <-> xq = xi+1, xi, xi-1
+    const bool okx[3] = {xi + 1 < W, true, xi > 0};
+    const int xq[3] = {xi + 1 < W ? xi + 1 : W - 1, xi, xi > 0 ? xi - 1 : 0};
+    float g[MP3_R + 2][3][V];
+    int a[MP3_R + 2][3][V];
 #pragma unroll
-    for (int k = 0; k < V; k++) acc[k] = 0.f;
-    // window centred at q = (yi - oy, xi - ox) sees this pixel at position (oy+1)*3 + (ox+1)
+    for (int r = 0; r < MP3_R + 2; r++) {
+      const int yq = y0 - 1 + r, yc = yq < 0 ? 0 : (yq >= H ? H - 1 : yq);
 #pragma unroll
-    for (int oy = -1; oy <= 1; oy++) {
-#pragma unroll
-      for (int ox = -1; ox <= 1; ox++) {
-        const int yq = yi - oy, xq = xi - ox;
-        if (yq < 0 || yq >= H || xq < 0 || xq >= W) continue;
-        const int64_t off = (((int64_t)b * H + yq) * W + xq) * C + cv * V;
-        float g[V];
-        vload<T, V>(dy + off, g);
-        const int pos = (oy + 1) * 3 + (ox + 1);
-#pragma unroll
-        for (int k = 0; k < V; k++) acc[k] += (arg[off + k] == pos) ? g[k] : 0.f;
+      for (int d = 0; d < 3; d++) {
+        const int64_t off = base + ((int64_t)yc * W + xq[d]) * C;
+        vload<T, V>(dy + off, g[r][d]);
+        load_positions<V>(arg + off, a[r][d]);
       }
     }
-    vstore<T, V>(dx + i * V, acc);
+    float acc[MP3_R][V];
+#pragma unroll
+    for (int j = 0; j < MP3_R; j++)
+#pragma unroll
+      for (int k = 0; k < V; k++) acc[j][k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < MP3_R + 2; r++) {
+      const int yq = y0 - 1 + r;
+      const bool oky = yq >= 0 && yq < H;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const bool ok = oky && okx[d];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const int j = r + t - 2;                       // the strip row this window's row t is
+          if (j < 0 || j >= MP3_R) continue;
+#pragma unroll
+          for (int k = 0; k < V; k++) acc[j][k] += (ok && a[r][d][k] == 3 * t + d) ? g[r][d][k] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MP3_R; j++) {
+      if (y0 + j >= H) continue;
+      vstore<T, V>(dx + base + ((int64_t)(y0 + j) * W + xi) * C, acc[j]);
+    }
   }
+}
+
+// ---- the same two passes for bf16 tensors of 8-channel vectors, on integer keys -------------------------
+// Both strip kernels above are bound by the vector ALU (a wave instruction takes four cycles: about 8 lane
+// instructions per byte of memory traffic at the streaming rate), not by memory.  These forms cut the
+// instruction count per output from about 80 to about 20:
+//   * a thread owns MP3_COLS adjacent columns and walks down `run` rows, so an input row is loaded and converted
+//     once per thread (plus one halo column each side and two halo rows per run);
+//   * forward, lazy input only: relu(z*scale + shift) rounded to bf16 is a non-negative number, its float32 bit
+//     pattern orders like the number, and the low 16 bits are free: key = bits | stamp, where the stamp
+//     MP3_STAMP - (4*row + column) (row, column counted inside the thread's patch) falls in scan order, makes
+//     `v_max3_u32` return the first maximum and where it was at once — one instruction per 3 taps horizontally,
+//     one vertically, nothing to add in between; padding has key 0 and never wins (every stamp is >= 4).
+//     (A -0 activation — the affine must produce -0 exactly — would order above every number: it is numerically
+//     a maximum whenever it wins against zeros only, so at worst a tie among zeros goes to it.)
+constexpr int MP3_COLS = 2;
+constexpr int MP3_RUN_MAX = 12;      // (4 .. 16 measure within 4 % of each other)
+constexpr unsigned MP3_STAMP = 4 * (MP3_RUN_MAX + 1) + 3 + 4;
+int g_mp3_strip_kernels = 0;      // test hook: 1 = the strip kernels for every input
+
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) {
+  unsigned d;
+  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(TPB) void maxpool3_fwd_keys_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                                uint8_t* __restrict__ arg, int B, int H, int W, int C,
+                                                                const float* __restrict__ in_aff, int run) {
+  constexpr int V = 8, NC = MP3_COLS + 2;
+  static_assert(NC <= 4, "the stamp gives the column two bits");
+  extern __shared__ float aff_lds[];
+  for (int i = threadIdx.x; i < 2 * C; i += TPB) aff_lds[i] = in_aff[i];
+  __syncthreads();
+  const unsigned CV = (unsigned)(C / V), WG = (unsigned)((W + MP3_COLS - 1) / MP3_COLS), HR = (unsigned)((H + run - 1) / run);
+  const unsigned total = (unsigned)B * HR * WG * CV;
+  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
+    const unsigned cv = i % CV;
+    unsigned p = i / CV;
+    const int x0 = (int)(p % WG) * MP3_COLS;
+    p /= WG;
+    const int ys = (int)(p % HR) * run, ye = ys + run < H ? ys + run : H;
+    const int b = (int)(p / HR);
+    float sc[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      sc[k] = aff_lds[cv * V + k];
+      sh[k] = aff_lds[C + cv * V + k];
+    }
+    const bf16* xb = x + (int64_t)b * H * W * C + cv * V;
+    int64_t coff[NC];
+#pragma unroll
+    for (int d = 0; d < NC; d++) {
+      const int xx = x0 - 1 + d;
+      coff[d] = (int64_t)(xx < 0 ? 0 : (xx >= W ? W - 1 : xx)) * C;
+    }
+    // the two halo columns (the others: see the stores); masks, not selects: a select on a per-thread condition
+    // invites the compiler to branch around the conversions, which splits the row into a dozen basic blocks
+    const unsigned m_first = x0 > 0 ? ~0u : 0u, m_last = x0 + MP3_COLS < W ? ~0u : 0u;
+    uint4 raw[NC];
+    auto issue = [&](int yy) {
+      const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
+      for (int d = 0; d < NC; d++) raw[d] = *reinterpret_cast<const uint4*>(xb + (int64_t)yc * W * C + coff[d]);
+    };
+    // raw -> the horizontal maxima of patch row r (image row ys - 1 + r); all 0 for a row outside the image
+    auto finish = [&](int r, unsigned (&hk)[MP3_COLS][V]) {
+      const int yy = ys - 1 + r;
+      const unsigned m_row = (yy >= 0 && yy < H) ? ~0u : 0u;
+      unsigned key[NC][V];
+#pragma unroll
+      for (int d = 0; d < NC; d++) {
+        const unsigned stamp = MP3_STAMP - (unsigned)(4 * r + d);
+        const unsigned w4[4] = {raw[d].x, raw[d].y, raw[d].z, raw[d].w};
+#pragma unroll
+        for (int k = 0; k < V; k += 2) {
+          f32x2 a;
+          a.x = fmaxf(__builtin_bit_cast(float, w4[k >> 1] << 16) * sc[k] + sh[k], 0.f);
+          a.y = fmaxf(__builtin_bit_cast(float, w4[k >> 1] & 0xFFFF0000u) * sc[k + 1] + sh[k + 1], 0.f);
+          const unsigned pr = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));   // two rounded values
+          key[d][k] = (pr << 16) | stamp;
+          key[d][k + 1] = (pr & 0xFFFF0000u) | stamp;
+        }
+        if (d == 0 || d == NC - 1) {
+          const unsigned m = d == 0 ? m_first : m_last;
+#pragma unroll
+          for (int k = 0; k < V; k++) key[d][k] &= m;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MP3_COLS; j++)
+#pragma unroll
+        for (int k = 0; k < V; k++) hk[j][k] = umax3(key[j][k], key[j + 1][k], key[j + 2][k]) & m_row;
+    };
+    // output row ys + q from patch rows q, q+1, q+2: window position = 3*(row - q) + (column - j), and
+    // 3*row + column = n - (n >> 2) for n = 4*row + column = MP3_STAMP - stamp, on four packed bytes at once
+    auto emit = [&](int q, const unsigned (&ha)[MP3_COLS][V], const unsigned (&hb)[MP3_COLS][V],
+                    const unsigned (&hc)[MP3_COLS][V]) {
+#pragma unroll
+      for (int j = 0; j < MP3_COLS; j++) {
+        unsigned key[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) key[k] = umax3(ha[j][k], hb[j][k], hc[j][k]);
+        if (x0 + j >= W) continue;
+        const int64_t o = (((int64_t)b * H + ys + q) * W + x0 + j) * C + cv * V;
+        uint4 val;   // the upper halves of two keys are two bf16 values
+        val.x = __builtin_amdgcn_perm(key[1], key[0], 0x07060302u);
+        val.y = __builtin_amdgcn_perm(key[3], key[2], 0x07060302u);
+        val.z = __builtin_amdgcn_perm(key[5], key[4], 0x07060302u);
+        val.w = __builtin_amdgcn_perm(key[7], key[6], 0x07060302u);
+        *reinterpret_cast<uint4*>(y + o) = val;
+        const unsigned first = (unsigned)(3 * q + j) * 0x01010101u;
+        uint2 pos;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const unsigned lo = __builtin_amdgcn_perm(key[4 * h + 1], key[4 * h], 0x0c0c0400u);
+          const unsigned hi = __builtin_amdgcn_perm(key[4 * h + 3], key[4 * h + 2], 0x0c0c0400u);
+          const unsigned n4 = MP3_STAMP * 0x01010101u - __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+          const unsigned p4 = n4 - ((n4 >> 2) & 0x3F3F3F3Fu) - first;
+          if (h == 0) pos.x = p4; else pos.y = p4;
+        }
+        *reinterpret_cast<uint2*>(arg + o) = pos;
+      }
+    };
+    unsigned h0[MP3_COLS][V], h1[MP3_COLS][V], h2[MP3_COLS][V];
+    issue(ys - 1);
+    finish(0, h0);
+    issue(ys);
+    finish(1, h1);
+    issue(ys + 1);
+    const int nq = ye - ys;
+    int q = 0;
+    while (true) {                                   // (each step loads the row after the one it converts)
+      finish(q + 2, h2); issue(ys + q + 2); emit(q, h0, h1, h2); if (++q >= nq) break;
+      finish(q + 2, h0); issue(ys + q + 2); emit(q, h1, h2, h0); if (++q >= nq) break;
+      finish(q + 2, h1); issue(ys + q + 2); emit(q, h2, h0, h1); if (++q >= nq) break;
+    }
+  }
+}
+
+// Backward on the same thread layout: the windows of row yq give to pixel rows yq-1, yq, yq+1 — three rolling
+// accumulator rows per thread; after window row yq pixel row yq-1 is complete.  A window outside the image gets
+// position 15, which matches nothing.
+__global__ __launch_bounds__(TPB) void maxpool3_bwd_run_kernel(const bf16* __restrict__ dy, const uint8_t* __restrict__ arg,
+                                                               bf16* __restrict__ dx, int B, int H, int W, int C, int run) {
+  constexpr int V = 8, NC = MP3_COLS + 2;
+  const unsigned CV = (unsigned)(C / V), WG = (unsigned)((W + MP3_COLS - 1) / MP3_COLS), HR = (unsigned)((H + run - 1) / run);
+  const unsigned total = (unsigned)B * HR * WG * CV;
+  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += gridDim.x * TPB) {
+    const unsigned cv = i % CV;
+    unsigned p = i / CV;
+    const int x0 = (int)(p % WG) * MP3_COLS;
+    p /= WG;
+    const int ys = (int)(p % HR) * run, ye = ys + run < H ? ys + run : H;
+    const int b = (int)(p / HR);
+    const int64_t base = (int64_t)b * H * W * C + cv * V;
+    int64_t coff[NC];
+    bool okc[NC];
+#pragma unroll
+    for (int d = 0; d < NC; d++) {
+      const int xx = x0 - 1 + d;
+      okc[d] = xx >= 0 && xx < W;
+      coff[d] = (int64_t)(xx < 0 ? 0 : (xx >= W ? W - 1 : xx)) * C;
+    }
+    uint4 graw[NC];
+    uint2 araw[NC];
+    auto issue = [&](int yq) {
+      const int yc = yq < 0 ? 0 : (yq >= H ? H - 1 : yq);
+#pragma unroll
+      for (int d = 0; d < NC; d++) {
+        const int64_t off = base + (int64_t)yc * W * C + coff[d];
+        graw[d] = *reinterpret_cast<const uint4*>(dy + off);
+        araw[d] = *reinterpret_cast<const uint2*>(arg + off);
+      }
+    };
+    // window row yq: pixel row yq-1 is the windows' row 0 (`up`), yq their row 1 (`mid`), yq+1 their row 2 (`down`)
+    auto add_row = [&](int yq, float (&up)[MP3_COLS][V], float (&mid)[MP3_COLS][V], float (&down)[MP3_COLS][V]) {
+      const bool oky = yq >= 0 && yq < H;
+#pragma unroll
+      for (int d = 0; d < NC; d++) {
+        const bool ok = oky && okc[d];
+        const unsigned g4[4] = {graw[d].x, graw[d].y, graw[d].z, graw[d].w};
+        const unsigned a2[2] = {ok ? araw[d].x : 0x0F0F0F0Fu, ok ? araw[d].y : 0x0F0F0F0Fu};
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          const float g = __builtin_bit_cast(float, (k & 1) ? (g4[k >> 1] & 0xFFFF0000u) : (g4[k >> 1] << 16));
+          const unsigned a = (a2[k >> 2] >> (8 * (k & 3))) & 255u;
+#pragma unroll
+          for (int j = 0; j < MP3_COLS; j++) {
+            const int u = j + 2 - d;                 // the window's column that pixel column x0 + j is
+            if (u < 0 || u > 2) continue;
+            up[j][k] += a == (unsigned)u ? g : 0.f;
+            mid[j][k] += a == (unsigned)(3 + u) ? g : 0.f;
+            down[j][k] += a == (unsigned)(6 + u) ? g : 0.f;
+          }
+        }
+      }
+    };
+    auto store = [&](int yp, float (&acc)[MP3_COLS][V]) {
+#pragma unroll
+      for (int j = 0; j < MP3_COLS; j++) {
+        if (yp >= ys && yp < ye && x0 + j < W) vstore<bf16, V>(dx + base + ((int64_t)yp * W + x0 + j) * C, acc[j]);
+#pragma unroll
+        for (int k = 0; k < V; k++) acc[j][k] = 0.f;        // the slot's next use: the row two below
+      }
+    };
+    float a0[MP3_COLS][V], a1[MP3_COLS][V], a2[MP3_COLS][V];
+#pragma unroll
+    for (int j = 0; j < MP3_COLS; j++)
+#pragma unroll
+      for (int k = 0; k < V; k++) a0[j][k] = a1[j][k] = a2[j][k] = 0.f;
+    issue(ys - 1);
+    int yq = ys - 1;
+    while (true) {
+      add_row(yq, a0, a1, a2); issue(yq + 1); store(yq - 1, a0); if (++yq > ye) break;
+      add_row(yq, a1, a2, a0); issue(yq + 1); store(yq - 1, a1); if (++yq > ye) break;
+      add_row(yq, a2, a0, a1); issue(yq + 1); store(yq - 1, a2); if (++yq > ye) break;
+    }
+  }
+}
+
+// rows per thread of the two kernels above: long runs (few halo rows) while the launch still has ~256 K threads
+static inline int mp3_run(int B, int H, int W, int C) {
+  const int64_t per_row = (int64_t)B * ((W + MP3_COLS - 1) / MP3_COLS) * (C / 8);
+  int run = (int)((per_row * H) / 262144);
+  if (run > MP3_RUN_MAX) run = MP3_RUN_MAX;
+  if (run < 4) run = 4;
+  return run < H ? run : H;
 }
 
 // ---- the four branch tensors ----------------------------------------------------------------
@@ -422,7 +701,15 @@ __global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn
   constexpr int ST_N = POOL ? 1 : ST_N_BWD;
   extern __shared__ float red[];             // [PL][ST_N][C]
   const int CV = C / V, PL = TPB / CV;
-  const int k = blockIdx.x & 3, r = (blockIdx.x >> 2) % rows, b = (blockIdx.x >> 2) / rows;
+  // The four branches of one pixel chunk read the same gradient chunk: when the chunk count allows it they get
+  // workgroup ids 8 apart (consecutive ids go round the 8 XCDs), so all four run on one XCD at about the same
+  // time and its L2 serves three of the four reads.
+  int k = blockIdx.x & 3, ch = blockIdx.x >> 2;
+  if (!POOL && ((B * rows) & 7) == 0) {
+    k = (blockIdx.x >> 3) & 3;
+    ch = ((blockIdx.x >> 5) << 3) | (blockIdx.x & 7);
+  }
+  const int r = ch % rows, b = ch / rows;
   const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, c0 = cv * V;
   const float* aff = br.aff[k];              // [4][C]: scale, shift, mean, rstd
   float acc[ST_N][V];
@@ -637,6 +924,12 @@ __global__ __launch_bounds__(TPB) void dw_compose_bwd_multi_kernel(const Compose
 
 extern "C" {
 
+int mis_set_maxpool3_path(int strip_kernels) {
+  const int before = g_mp3_strip_kernels;
+  g_mp3_strip_kernels = strip_kernels ? 1 : 0;
+  return before;
+}
+
 int mis_maxpool3x3s1_fwd(const void* x, const float* x_affine, int dtype, int B, int H, int W, int C, void* y,
                          uint8_t* argmax, mis_stream_t stream) {
   MIS_REQUIRE(x && y && argmax, "maxpool3x3s1_fwd: null pointer");
@@ -647,7 +940,11 @@ int mis_maxpool3x3s1_fwd(const void* x, const float* x_affine, int dtype, int B,
   const int64_t n = (int64_t)B * ((H + MP3_R - 1) / MP3_R) * W * C;
   MIS_REQUIRE(n < ((int64_t)1 << 31), "maxpool3x3s1_fwd: tensor too large for 32-bit item arithmetic");
   if (dtype == MIS_BF16) {
-    if (pick_vec<bf16>(C, x, y, argmax) == 8)
+    if (x_affine && pick_vec<bf16>(C, x, y, argmax) == 8 && !g_mp3_strip_kernels) {
+      const int run = mp3_run(B, H, W, C);
+      const int64_t items = (int64_t)B * ((H + run - 1) / run) * ((W + MP3_COLS - 1) / MP3_COLS) * (C / 8);
+      maxpool3_fwd_keys_kernel<<<ew_grid(items, TPB), TPB, lds, st>>>((const bf16*)x, (bf16*)y, argmax, B, H, W, C, x_affine, run);
+    } else if (pick_vec<bf16>(C, x, y, argmax) == 8)
       maxpool3_fwd_kernel<bf16, 8><<<ew_grid(n / 8, TPB), TPB, lds, st>>>((const bf16*)x, (bf16*)y, argmax, B, H, W, C, x_affine);
     else
       maxpool3_fwd_kernel<bf16, 1><<<ew_grid(n, TPB), TPB, lds, st>>>((const bf16*)x, (bf16*)y, argmax, B, H, W, C, x_affine);
@@ -668,14 +965,20 @@ int mis_maxpool3x3s1_bwd(const void* dy, const uint8_t* argmax, int dtype, int B
   MIS_REQUIRE(dy && argmax && dx, "maxpool3x3s1_bwd: null pointer");
   MIS_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, "maxpool3x3s1_bwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t n = (int64_t)B * H * W * C;
+  // items as in the forward pass
+  const int64_t n = (int64_t)B * ((H + MP3_R - 1) / MP3_R) * W * C;
+  MIS_REQUIRE(n < ((int64_t)1 << 31), "maxpool3x3s1_bwd: tensor too large for 32-bit item arithmetic");
   if (dtype == MIS_BF16) {
-    if (pick_vec<bf16>(C, dy, dx) == 8)
+    if (pick_vec<bf16>(C, dy, dx, argmax) == 8 && !g_mp3_strip_kernels) {
+      const int run = mp3_run(B, H, W, C);
+      const int64_t items = (int64_t)B * ((H + run - 1) / run) * ((W + MP3_COLS - 1) / MP3_COLS) * (C / 8);
+      maxpool3_bwd_run_kernel<<<ew_grid(items, TPB), TPB, 0, st>>>((const bf16*)dy, argmax, (bf16*)dx, B, H, W, C, run);
+    } else if (pick_vec<bf16>(C, dy, dx, argmax) == 8)
       maxpool3_bwd_kernel<bf16, 8><<<ew_grid(n / 8, TPB), TPB, 0, st>>>((const bf16*)dy, argmax, (bf16*)dx, B, H, W, C);
     else
       maxpool3_bwd_kernel<bf16, 1><<<ew_grid(n, TPB), TPB, 0, st>>>((const bf16*)dy, argmax, (bf16*)dx, B, H, W, C);
   } else if (dtype == MIS_F32) {
-    if (pick_vec<float>(C, dy, dx) == 4)
+    if (pick_vec<float>(C, dy, dx, argmax) == 4)
       maxpool3_bwd_kernel<float, 4><<<ew_grid(n / 4, TPB), TPB, 0, st>>>((const float*)dy, argmax, (float*)dx, B, H, W, C);
     else
       maxpool3_bwd_kernel<float, 1><<<ew_grid(n, TPB), TPB, 0, st>>>((const float*)dy, argmax, (float*)dx, B, H, W, C);

@@ -79,6 +79,44 @@ def test_maxpool3x3_row_strips(dtype, shape, lazy):
     assert rel_err(zd.grad, ar.grad) < (1e-6 if dtype == torch.float32 else 1e-2)   # gradient w.r.t. the activation
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 9, 13), (1, 16, 37, 6), (3, 32, 20, 33), (1, 64, 5, 2), (16, 32, 512, 512),
+                                   (16, 256, 64, 64)])
+def test_maxpool3x3_key_kernels_equal_strip_kernels(shape):
+    """bf16 tensors of 8-channel vectors: the integer-key forward (lazy input) and the row-run backward against the
+    generic strip kernels — values, recorded window positions and gradients bit for bit (up to the order in which
+    a pixel's <= 9 float32 contributions are added: the gradient is compared after both were rounded to bf16, where
+    at most the last bit may differ).  The two large shapes are A_UNet's top and bottom levels: rows per thread
+    12 and 4."""
+    from medical_image_segmentation_amd import functional as F_
+    from medical_image_segmentation_amd import _lib
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(B * 7 + H)
+    z = (torch.randint(-6, 7, shape, generator=g).float() * 0.25).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    scale = torch.tensor([(-1.0) ** c * (0.5 + 0.25 * (c % 3)) for c in range(C)])
+    shift = torch.tensor([0.25 * ((c % 5) - 2) for c in range(C)])
+    ss = torch.stack([scale, shift]).to(DEV)
+    gy = torch.randn(shape, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out = []
+    for strips in (1, 0):
+        before = _lib.query("mis_set_maxpool3_path", strips)
+        try:
+            y, arg, dx = torch.empty_like(z), torch.empty(z.numel(), dtype=torch.uint8, device=DEV), torch.empty_like(z)
+            _lib.call("mis_maxpool3x3s1_fwd", z.data_ptr(), ss.data_ptr(), F_._dt(z), B, H, W, C, y.data_ptr(), arg.data_ptr(),
+                      F_._stream())
+            _lib.call("mis_maxpool3x3s1_bwd", gy.data_ptr(), arg.data_ptr(), F_._dt(z), B, H, W, C, dx.data_ptr(), F_._stream())
+            torch.cuda.synchronize()
+            out.append((y, arg, dx))
+        finally:
+            _lib.query("mis_set_maxpool3_path", before)
+    (y0, a0, d0), (y1, a1, d1) = out
+    assert torch.equal(y0, y1)
+    assert torch.equal(a0, a1)
+    assert int(a1.max()) <= 8
+    diff = (d0.float() - d1.float()).abs()
+    assert float((diff / d0.float().abs().clamp_min(1e-3)).max()) <= 2 ** -7
+    assert float((diff > 0).float().mean()) < 1e-2
+
+
 def test_amsfn_block_golden(golden):
     from medical_image_segmentation_amd.model.utils.modules import AMSFN
     g = golden("a_unet")
