@@ -693,13 +693,18 @@ constexpr int ST_N_BWD = 5;
 
 // Workgroup = (branch k, sample b, pixel chunk r); thread = (channel vector cv, pixel lane pl) walking a
 // contiguous chunk.  partials[r][q][b][k*C + c]; fixed-order LDS tree.
-// POOL: only sum a (g unused, NQ = 1) — the global average pool of the forward pass, scaled by `scale`.
+// POOL: only sum a (g unused, one sum) — the global average pool of the forward pass, scaled by `scale`.
+// Backward: the pass is bound by the vector ALU, not by memory (a wave instruction takes four cycles), so it
+// accumulates q1..q4 only — with the mask as a float factor, 12 instructions per element — and forms
+// q0 = sum a*g per workgroup as gamma*q2 + beta*q1: a = [y>0]*(gamma*xhat + beta) before its rounding to the
+// storage type, so in float32 this is q0 up to the order of the additions, and in bf16 it is the gradient with
+// respect to the unrounded activation (the rounding error of a is unbiased and relative 2^-9 per element).
 template <typename T, int V, bool POOL = false>
 __global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn bn, const T* __restrict__ g, int B,
                                                            int HW, int C, int rows, int chunk,
                                                            float* __restrict__ partials, float scale = 1.f) {
-  constexpr int ST_N = POOL ? 1 : ST_N_BWD;
-  extern __shared__ float red[];             // [PL][ST_N][C]
+  constexpr int NQ = POOL ? 1 : ST_N_BWD - 1;      // sums accumulated per element
+  extern __shared__ float red[];             // [PL][NQ][C]
   const int CV = C / V, PL = TPB / CV;
   // The four branches of one pixel chunk read the same gradient chunk: when the chunk count allows it they get
   // workgroup ids 8 apart (consecutive ids go round the 8 XCDs), so all four run on one XCD at about the same
@@ -712,61 +717,80 @@ __global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn
   const int r = ch % rows, b = ch / rows;
   const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, c0 = cv * V;
   const float* aff = br.aff[k];              // [4][C]: scale, shift, mean, rstd
-  float acc[ST_N][V];
+  float acc[NQ][V];
 #pragma unroll
-  for (int q = 0; q < ST_N; q++)
+  for (int q = 0; q < NQ; q++)
 #pragma unroll
     for (int j = 0; j < V; j++) acc[q][j] = 0.f;
   if (pl < PL) {
-    float sc[V], sh[V], mu[POOL ? 1 : V], rs[POOL ? 1 : V], ga[POOL ? 1 : V], be[POOL ? 1 : V];
+    const T* zk = (const T*)br.z[k];
+    const int p1 = (r + 1) * chunk < HW ? (r + 1) * chunk : HW;
+    if constexpr (POOL) {
+      float sc[V], sh[V];
 #pragma unroll
-    for (int j = 0; j < V; j++) {
-      sc[j] = aff ? aff[c0 + j] : 1.f;
-      sh[j] = aff ? aff[C + c0 + j] : 0.f;
-      if constexpr (!POOL) {
+      for (int j = 0; j < V; j++) {
+        sc[j] = aff ? aff[c0 + j] : 1.f;
+        sh[j] = aff ? aff[C + c0 + j] : 0.f;
+      }
+#pragma unroll 2
+      for (int p = r * chunk + pl; p < p1; p += PL) {
+        float zv[V];
+        vload<T, V>(zk + ((int64_t)b * HW + p) * C + c0, zv);
+        // the activation as consumers read it (a plain branch tensor has no affine)
+#pragma unroll
+        for (int j = 0; j < V; j++)
+          acc[0][j] += aff ? to_f32(from_f32<T>(fmaxf(zv[j] * sc[j] + sh[j], 0.f))) : zv[j];
+      }
+    } else {
+      float mu[V], rs[V], ga[V], be[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) {
         mu[j] = aff[2 * C + c0 + j];
         rs[j] = aff[3 * C + c0 + j];
         ga[j] = bn.gamma[k][c0 + j];
         be[j] = bn.beta[k][c0 + j];
       }
-    }
-    const T* zk = (const T*)br.z[k];
-    const int p1 = (r + 1) * chunk < HW ? (r + 1) * chunk : HW;
 #pragma unroll 2
-    for (int p = r * chunk + pl; p < p1; p += PL) {
-      const int64_t idx = ((int64_t)b * HW + p) * C + c0;
-      float gv[V], zv[V];
-      if constexpr (!POOL) vload<T, V>(g + idx, gv);
-      vload<T, V>(zk + idx, zv);
+      for (int p = r * chunk + pl; p < p1; p += PL) {
+        const int64_t idx = ((int64_t)b * HW + p) * C + c0;
+        float gv[V], zv[V];
+        vload<T, V>(g + idx, gv);
+        vload<T, V>(zk + idx, zv);
 #pragma unroll
-      for (int j = 0; j < V; j++) {
-        // the activation as consumers read it (a plain branch tensor has no affine)
-        const float a = aff ? to_f32(from_f32<T>(fmaxf(zv[j] * sc[j] + sh[j], 0.f))) : zv[j];
-        if constexpr (POOL) {
-          acc[0][j] += a;
-        } else {
+        for (int j = 0; j < V; j++) {
           const float xh = (zv[j] - mu[j]) * rs[j];
-          const bool on = xh * ga[j] + be[j] > 0.f;                                  // the mask of the layer's dz kernel
-          const float dy = on ? gv[j] : 0.f;
-          acc[0][j] += a * gv[j];
-          acc[1][j] += dy;
-          acc[2][j] += dy * xh;
-          acc[3][j] += on ? 1.f : 0.f;
-          acc[4][j] += on ? xh : 0.f;
+          const float on = xh * ga[j] + be[j] > 0.f ? 1.f : 0.f;          // the mask of the layer's dz kernel
+          const float dy = on * gv[j];
+          acc[0][j] += dy;
+          acc[1][j] = fmaf(dy, xh, acc[1][j]);
+          acc[2][j] += on;
+          acc[3][j] = fmaf(on, xh, acc[3][j]);
         }
       }
     }
 #pragma unroll
-    for (int q = 0; q < ST_N; q++)
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
-      for (int j = 0; j < V; j++) red[(pl * ST_N + q) * C + c0 + j] = acc[q][j];
+      for (int j = 0; j < V; j++) red[(pl * NQ + q) * C + c0 + j] = acc[q][j];
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < ST_N * C; e += TPB) {
+  const int q0 = POOL ? 0 : 1;               // plane of the first accumulated sum
+  const int planes = POOL ? 1 : ST_N_BWD;
+  for (int e = threadIdx.x; e < NQ * C; e += TPB) {
     float t = 0.f;
-    for (int q = 0; q < PL; q++) t += red[q * ST_N * C + e];
+    for (int q = 0; q < PL; q++) t += red[q * NQ * C + e];
     const int qq = e / C, c = e % C;
-    partials[(((int64_t)r * ST_N + qq) * B + b) * 4 * C + k * C + c] = t * scale;
+    partials[(((int64_t)r * planes + q0 + qq) * B + b) * 4 * C + k * C + c] = t * scale;
+  }
+  if constexpr (!POOL) {
+    for (int c = threadIdx.x; c < C; c += TPB) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int q = 0; q < PL; q++) {
+        t1 += red[q * NQ * C + c];
+        t2 += red[(q * NQ + 1) * C + c];
+      }
+      partials[(((int64_t)r * planes) * B + b) * 4 * C + k * C + c] = bn.gamma[k][c] * t2 + bn.beta[k][c] * t1;
+    }
   }
 }
 
