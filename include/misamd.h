@@ -367,6 +367,17 @@ int mis_bn_relu_bwd_dz_scaled(const void* z, const void* g, const float* g_scale
                               int64_t hw, int dtype, int64_t n_pix, int C, const float* mean_rstd, const float* gamma,
                               const float* beta, const float* sums, void* dz, float* dbias, void* workspace,
                               mis_stream_t stream);
+/* The same for all four branch layers of one block in ONE launch (g is then read from  */
+/* memory once, not four times): z, mean_rstd, gamma, beta, dz, rows are HOST arrays of   */
+/* 4 device pointers; g_scale / g_shift are the [B][4*C] tables of the block (branch k    */
+/* at column k*C, coef_ld >= 4*C); sums is [4][2][C]; rows[k] is NULL or a                */
+/* [mis_bn_relu_bwd_dz_rows(dtype, n_pix, C)][C] buffer that receives the partial rows    */
+/* of the conv-bias gradient (summed by the caller or by the weight-gradient reduction).  */
+/* Results are bit-identical to four mis_bn_relu_bwd_dz_scaled calls.                     */
+int mis_bn_relu_bwd_dz_scaled4(const void* const* z, const void* g, const float* g_scale, const float* g_shift,
+                               int coef_ld, int64_t hw, int dtype, int64_t n_pix, int C,
+                               const float* const* mean_rstd, const float* const* gamma, const float* const* beta,
+                               const float* sums, void* const* dz, float* const* rows, mis_stream_t stream);
 /* The same two passes for a BatchNorm2d that is NOT followed by a ReLU of its own  */
 /* (ResDConv's `c1` and `cbr3`, model/utils/modules.py:432-433,444-445): dy is the    */
 /* gradient of the BatchNorm output as it is, no mask.                               */

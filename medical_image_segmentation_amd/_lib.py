@@ -74,6 +74,7 @@ PROTOTYPES = {
     "mis_bn_relu_bwd_dz_head": (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_relu_bwd_dz_scaled": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mis_bn_relu_bwd_dz_scaled4": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_bwd_reduce": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_bn_bwd_dz": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mis_add_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),

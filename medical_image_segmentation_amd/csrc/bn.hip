@@ -211,21 +211,19 @@ struct ChannelSum {
 // (the backward of a per-sample weighted sum plus a global average pool: the AMSFN fusion): formed on load
 // in float32, so no per-branch gradient tensor exists.  `head_w` carries g_scale.
 constexpr int HEAD_MAX_CO = 8;
-template <typename T, int V, bool HEAD = false, int HCO = HEAD_MAX_CO, bool SCALED = false>
-__global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __restrict__ z, const T* __restrict__ da,
-                                                                    T* __restrict__ dz, int64_t n_vec, int C,
-                                                                    float inv_n, const float* __restrict__ mean_rstd,
-                                                                    const float* __restrict__ gamma,
-                                                                    const float* __restrict__ beta,
-                                                                    const float* __restrict__ sums,
-                                                                    float* __restrict__ dz_partials, int relu,
-                                                                    const float* __restrict__ head_w = nullptr,
-                                                                    int head_co = 0,
-                                                                    const float* __restrict__ g_shift = nullptr,
-                                                                    int coef_ld = 0, unsigned px_per_sample = 1) {
+// (block, n_blocks: the workgroup's index and count inside ITS tensor's launch — a launch may carry several tensors)
+template <typename T, int V, bool HEAD, int HCO, bool SCALED>
+__device__ __forceinline__ void bn_relu_bwd_dz_body(const T* __restrict__ z, const T* __restrict__ da,
+                                                    T* __restrict__ dz, int64_t n_vec, int C, float inv_n,
+                                                    const float* __restrict__ mean_rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ sums, float* __restrict__ dz_partials,
+                                                    int relu, const float* __restrict__ head_w, int head_co,
+                                                    const float* __restrict__ g_shift, int coef_ld,
+                                                    unsigned px_per_sample, unsigned block, unsigned n_blocks) {
   extern __shared__ float prm[];   // scratch for the optional bias partial: [256][V]
   const int CV = C / V;
-  const int64_t i0 = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  const int64_t i0 = (int64_t)block * EW_THREADS + threadIdx.x;
   const int c0 = (int)(i0 % CV) * V;
   // (HCO: compile-time bound of head_co, so the 4-class head keeps 4 weight rows in registers, not 8)
   float hw[HEAD ? HCO : 1][V];
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
   // HEAD: the grid keeps a thread on one channel vector (its stride is a multiple of CV), so the pixel
   // index advances by a constant: no division in the loop
   int64_t pix = i0 / CV;
-  const int64_t pix_step = ((int64_t)gridDim.x * EW_THREADS) / CV;
+  const int64_t pix_step = ((int64_t)n_blocks * EW_THREADS) / CV;
   // SCALED: the tables' rows of the current sample stay in registers; the pixel index inside the sample is
   // tracked by additions (no division in the loop), and the rows are reloaded when it wraps
   float gsc[SCALED ? V : 1], gsh[SCALED ? V : 1];
@@ -267,7 +265,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
       gsh[k] = g_shift[row + k];
     }
   }
-  for (int64_t i = i0; i < n_vec; i += (int64_t)gridDim.x * EW_THREADS, pix += pix_step) {
+  for (int64_t i = i0; i < n_vec; i += (int64_t)n_blocks * EW_THREADS, pix += pix_step) {
     float zv[V], gv[V], o[V];
     vload<T, V>(z + i * V, zv);
     if constexpr (HEAD) {
@@ -325,19 +323,66 @@ __global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __r
     vstore<T, V>(dz + i * V, o);
   }
   if (dz_partials) {
-    // fixed-order block reduction: thread t holds channel vector (blockIdx*256 + t) % CV
+    // fixed-order block reduction: thread t holds channel vector (block*256 + t) % CV
     float* red = prm;                          // [256][V]
 #pragma unroll
     for (int k = 0; k < V; k++) red[threadIdx.x * V + k] = bsum[k];
     __syncthreads();
-    const int base = (int)(((int64_t)blockIdx.x * EW_THREADS) % CV);
+    const int base = (int)(((int64_t)block * EW_THREADS) % CV);
     for (int j = threadIdx.x; j < C; j += EW_THREADS) {
       const int cv = j / V, k = j % V;
       float acc = 0.f;
       for (int t = (cv - base + CV) % CV; t < EW_THREADS; t += CV) acc += red[t * V + k];
-      dz_partials[(int64_t)blockIdx.x * C + j] = acc;
+      dz_partials[(int64_t)block * C + j] = acc;
     }
   }
+}
+
+
+template <typename T, int V, bool HEAD = false, int HCO = HEAD_MAX_CO, bool SCALED = false>
+__global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_kernel(const T* __restrict__ z, const T* __restrict__ da,
+                                                                    T* __restrict__ dz, int64_t n_vec, int C,
+                                                                    float inv_n, const float* __restrict__ mean_rstd,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta,
+                                                                    const float* __restrict__ sums,
+                                                                    float* __restrict__ dz_partials, int relu,
+                                                                    const float* __restrict__ head_w = nullptr,
+                                                                    int head_co = 0,
+                                                                    const float* __restrict__ g_shift = nullptr,
+                                                                    int coef_ld = 0, unsigned px_per_sample = 1) {
+  bn_relu_bwd_dz_body<T, V, HEAD, HCO, SCALED>(z, da, dz, n_vec, C, inv_n, mean_rstd, gamma, beta, sums, dz_partials, relu,
+                                               head_w, head_co, g_shift, coef_ld, px_per_sample, blockIdx.x, gridDim.x);
+}
+
+// The four branch layers of one AMSFN block in ONE launch: every branch's gradient is formed from the same tensor
+// g (scaled mode), so the four workgroups that walk the same positions of g get ids 8 apart (consecutive ids go
+// round the 8 XCDs): they run on one XCD at about the same time and g is fetched from memory once, not four times.
+struct DzBranches {
+  const void* z[4];
+  void* dz[4];
+  const float* mean_rstd[4];
+  const float* gamma[4];
+  const float* beta[4];
+  const float* sums[4];         // [2][C] each
+  float* partials[4];           // [blocks per branch][C] each, or null
+};
+template <typename T, int V>
+__global__ __launch_bounds__(EW_THREADS) void bn_relu_bwd_dz_scaled4_kernel(DzBranches br, const T* __restrict__ g,
+                                                                            int64_t n_vec, int C, float inv_n,
+                                                                            const float* __restrict__ g_scale,
+                                                                            const float* __restrict__ g_shift,
+                                                                            int coef_ld, unsigned px_per_sample) {
+  const unsigned per_branch = gridDim.x >> 2;
+  unsigned k = blockIdx.x / per_branch, block = blockIdx.x % per_branch;
+  if ((per_branch & 7) == 0) {
+    k = (blockIdx.x >> 3) & 3;
+    block = ((blockIdx.x >> 5) << 3) | (blockIdx.x & 7);
+  }
+  bn_relu_bwd_dz_body<T, V, false, HEAD_MAX_CO, true>((const T*)br.z[k], g, (T*)br.dz[k], n_vec, C, inv_n, br.mean_rstd[k],
+                                                      br.gamma[k], br.beta[k], br.sums[k], br.partials[k], 1,
+                                                      g_scale + k * C, 0, g_shift + k * C, coef_ld, px_per_sample, block,
+                                                      per_branch);
 }
 
 template <typename T>
@@ -551,6 +596,56 @@ int mis_bn_relu_bwd_dz_scaled(const void* z, const void* g, const float* g_scale
               "bn_relu_bwd_dz_scaled: n_pix must be a whole number of samples of hw pixels, below 2^31");
   return bn_bwd_dz_any(z, g, dtype, n_pix, C, mean_rstd, gamma, beta, sums, dz, dbias, workspace, stream, 1, g_scale, 0,
                        g_shift, coef_ld, hw);
+}
+
+int mis_bn_relu_bwd_dz_scaled4(const void* const* z, const void* g, const float* g_scale, const float* g_shift,
+                               int coef_ld, int64_t hw, int dtype, int64_t n_pix, int C,
+                               const float* const* mean_rstd, const float* const* gamma, const float* const* beta,
+                               const float* sums, void* const* dz, float* const* rows, mis_stream_t stream) {
+  MIS_REQUIRE(z && g && g_scale && g_shift && mean_rstd && gamma && beta && sums && dz && rows,
+              "bn_relu_bwd_dz_scaled4: null pointer");
+  MIS_REQUIRE(coef_ld >= 4 * C, "bn_relu_bwd_dz_scaled4: the tables hold four branches per row, row stride >= 4*C");
+  MIS_REQUIRE(n_pix >= 1 && C >= 1 && C <= 2048, "bn_relu_bwd_dz_scaled4: bad shape");
+  MIS_REQUIRE(hw >= 1 && n_pix % hw == 0 && n_pix < ((int64_t)1 << 31),
+              "bn_relu_bwd_dz_scaled4: n_pix must be a whole number of samples of hw pixels, below 2^31");
+  MIS_REQUIRE(dtype == MIS_F32 || dtype == MIS_BF16, "bn_relu_bwd_dz_scaled4: bad dtype %d", dtype);
+  DzBranches br;
+  uintptr_t align = (uintptr_t)g;
+  for (int k = 0; k < 4; k++) {
+    MIS_REQUIRE(z[k] && dz[k] && mean_rstd[k] && gamma[k] && beta[k], "bn_relu_bwd_dz_scaled4: null pointer (branch %d)", k);
+    br.z[k] = z[k];
+    br.dz[k] = dz[k];
+    br.mean_rstd[k] = mean_rstd[k];
+    br.gamma[k] = gamma[k];
+    br.beta[k] = beta[k];
+    br.sums[k] = sums + (size_t)k * 2 * C;
+    br.partials[k] = rows[k];
+    align |= (uintptr_t)z[k] | (uintptr_t)dz[k];
+  }
+  const int N = dtype == MIS_F32 ? VecOf<float>::N : VecOf<bf16>::N;
+  const bool vec = C % N == 0 && (align % 16) == 0;
+  // (the partial rows are [mis_bn_relu_bwd_dz_rows][C]: that count assumes full vectors whenever C allows them)
+  MIS_REQUIRE(vec || C % N != 0, "bn_relu_bwd_dz_scaled4: tensors must be 16-byte aligned");
+  const int V = vec ? N : 1;
+  const int64_t n = n_pix * C;
+  const int per_branch = bwd_dz_grid(n, C, V);
+  const size_t lds = (size_t)EW_THREADS * N * sizeof(float);
+  const float inv_n = (float)(1.0 / (double)n_pix);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MIS_BF16 && vec)
+    bn_relu_bwd_dz_scaled4_kernel<bf16, 8><<<4 * per_branch, EW_THREADS, lds, st>>>(br, (const bf16*)g, n / 8, C, inv_n, g_scale,
+                                                                                    g_shift, coef_ld, (unsigned)hw);
+  else if (dtype == MIS_BF16)
+    bn_relu_bwd_dz_scaled4_kernel<bf16, 1><<<4 * per_branch, EW_THREADS, lds, st>>>(br, (const bf16*)g, n, C, inv_n, g_scale,
+                                                                                    g_shift, coef_ld, (unsigned)hw);
+  else if (vec)
+    bn_relu_bwd_dz_scaled4_kernel<float, 4><<<4 * per_branch, EW_THREADS, lds, st>>>(br, (const float*)g, n / 4, C, inv_n, g_scale,
+                                                                                     g_shift, coef_ld, (unsigned)hw);
+  else
+    bn_relu_bwd_dz_scaled4_kernel<float, 1><<<4 * per_branch, EW_THREADS, lds, st>>>(br, (const float*)g, n, C, inv_n, g_scale,
+                                                                                     g_shift, coef_ld, (unsigned)hw);
+  MIS_CHECK_LAUNCH("bn_relu_bwd_dz_scaled4_kernel");
+  return MIS_OK;
 }
 
 int mis_bn_bwd_dz(const void* z, const void* dy, int dtype, int64_t n_pix, int C, const float* mean_rstd,

@@ -365,6 +365,8 @@ class ComposedWeights:
 
     def __del__(self):
         entries = getattr(self, "entries", ())
+        if _COMPOSED is None or _COMPOSED_W is None:        # interpreter shutdown: the module's globals are gone
+            return
         for table, keys in ((_COMPOSED, [e[0] for e in entries]), (_COMPOSED_W, [e[2].data_ptr() for e in entries])):
             for k in keys:
                 hit = table.get(k)
@@ -850,16 +852,20 @@ class BranchGradLink:
     (mis_bn_relu_bwd_dz_scaled).  The tensor autograd hands the layer is dout itself, as a placeholder that
     must arrive untouched: with another consumer of the branch autograd would add to it, and the layer's
     backward raises."""
-    __slots__ = ("gamma", "beta", "g", "scale_ptr", "shift_ptr", "ld", "sums", "keep", "ptr", "version")
+    __slots__ = ("gamma", "beta", "g", "scale_ptr", "shift_ptr", "ld", "sums", "keep", "ptr", "version", "want_rows",
+                 "dz", "rows")
 
     def __init__(self):
         self.gamma = self.beta = self.g = self.sums = self.keep = None
         self.scale_ptr = self.shift_ptr = self.ld = 0
         self.ptr = self.version = -1
+        self.want_rows = False        # the layer wants its conv-bias gradient (known in its forward pass)
+        self.dz = self.rows = None    # FUSE_AMSFN_DZ4: the fusion node has already run the layer's dz kernel
 
 
 CENTER_TAP_CONVS = True  # 1x1 convs carried as 3x3 multiply their centre tap only (module attribute: the tests compare)
 FUSE_AMSFN_BWD = True    # (module attribute: the tests compare with the form that writes the four branch gradients)
+FUSE_AMSFN_DZ4 = True    # the four branch layers' dz kernels as ONE launch from the fusion node (the tests compare)
 
 
 # Order of a layer's two backward convs: weight gradient first.  The data gradient is then the last kernel of the
@@ -937,6 +943,8 @@ class ConvBnReluFn(torch.autograd.Function):
         ctx.link = link if (link is not None and relu and training and FUSE_AMSFN_BWD) else None
         if ctx.link is not None:
             link.gamma, link.beta, link.g = gamma.detach(), beta.detach(), None
+            link.want_rows = bias is not None and ctx.needs_input_grad[5]
+            link.dz = link.rows = None
         ctx.mark_non_differentiable(ss)
         return z, ss
 
@@ -975,7 +983,7 @@ class ConvBnReluFn(torch.autograd.Function):
         dgamma, dbeta = sums[1], sums[0]          # rows of one buffer; nothing below writes it
         # eval mode: statistics are constants, so the two projection terms vanish
         proj = sums if ctx.training else torch.zeros_like(sums)
-        dz = torch.empty_like(z)
+        dz = link.dz if (link is not None and link.dz is not None) else torch.empty_like(z)
         want_db = ctx.has_bias and ctx.needs_input_grad[5]
         want_dw = ctx.needs_input_grad[4]
         # The conv-bias gradient (sum of dz) leaves this kernel as per-workgroup rows.  When a weight
@@ -983,7 +991,13 @@ class ConvBnReluFn(torch.autograd.Function):
         # shared workspace is overwritten by the weight-gradient slabs); else they are reduced here.
         dbias = rows = None
         dz_ws = ws
-        if want_db and want_dw:
+        if link is not None and link.dz is not None:
+            # the fusion node ran this layer's dz kernel with its three siblings'; the bias rows came with it
+            if want_db and want_dw:
+                rows, n_rows = link.rows, link.rows.shape[0]
+            elif want_db:
+                dbias = link.rows.sum(0)
+        elif want_db and want_dw:
             n_rows = query("mis_bn_relu_bwd_dz_rows", _dt(x), n_pix, Cout)
             rows = torch.empty((n_rows, Cout), dtype=torch.float32, device=x.device)
             dz_ws = rows
@@ -997,11 +1011,13 @@ class ConvBnReluFn(torch.autograd.Function):
                      rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
             head.dy = head.w = head.sums = None
         elif link is not None:
-            with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
-                call("mis_bn_relu_bwd_dz_scaled", z.data_ptr(), link.g.data_ptr(), link.scale_ptr, link.shift_ptr, link.ld,
-                     H * W, _dt(x), n_pix, Cout, mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), proj.data_ptr(),
-                     dz.data_ptr(), rows.data_ptr() if rows is not None else _p(dbias), dz_ws.data_ptr(), st)
-            link.g = link.sums = link.keep = None
+            if link.dz is None:
+                with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
+                    call("mis_bn_relu_bwd_dz_scaled", z.data_ptr(), link.g.data_ptr(), link.scale_ptr, link.shift_ptr,
+                         link.ld, H * W, _dt(x), n_pix, Cout, mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                         proj.data_ptr(), dz.data_ptr(), rows.data_ptr() if rows is not None else _p(dbias),
+                         dz_ws.data_ptr(), st)
+            link.g = link.sums = link.keep = link.dz = link.rows = None
         else:
             with _prof("bn_relu_bwd_dz", 0, 3 * z.numel() * z.element_size()):
                 call("mis_bn_relu_bwd_dz" if relu else "mis_bn_bwd_dz", z.data_ptr(), da.data_ptr(), _dt(x), n_pix, Cout,
@@ -1501,6 +1517,19 @@ class AmsfnFuseFn(torch.autograd.Function):
                 l.g, l.sums, l.keep = dout, bn_sums[k], (w, shift)
                 l.scale_ptr, l.shift_ptr, l.ld = w.data_ptr() + 4 * k * Cc, shift.data_ptr() + 4 * k * Cc, 4 * Cc
                 l.ptr, l.version = dout.data_ptr(), dout._version
+            if FUSE_AMSFN_DZ4:
+                # the four layers' dz kernels read the same dout: one launch, dout fetched once
+                n_pix = B * H * W
+                n_rows = query("mis_bn_relu_bwd_dz_rows", _dt(z1), n_pix, Cc)
+                dzs = [torch.empty_like(z1) for _ in range(4)]
+                rows = [torch.empty((n_rows, Cc), dtype=torch.float32, device=dev) if l.want_rows else None for l in links]
+                with _prof("bn_relu_bwd_dz", 0, 9 * z1.numel() * z1.element_size()):
+                    call("mis_bn_relu_bwd_dz_scaled4", _ptr_array(zs), dout.data_ptr(), w.data_ptr(), shift.data_ptr(),
+                         4 * Cc, H * W, _dt(z1), n_pix, Cc, _ptr_array([t[2:] for t in sss]),
+                         _ptr_array([l.gamma for l in links]), _ptr_array([l.beta for l in links]), bn_sums.data_ptr(),
+                         _ptr_array(dzs), _ptr_array(rows), _stream())
+                for k, l in enumerate(links):
+                    l.dz, l.rows = dzs[k], rows[k]
             return (dout, None, dout, None, dout, None, dout, None, dW1.reshape(s1s), db1, dW2.reshape(s2s), db2, None)
         dact = [torch.empty_like(z1) for _ in range(4)]
         ws = workspace(query("mis_amsfn_workspace_bytes", B, H * W, Cc), dev)

@@ -37,7 +37,7 @@ def _isolated_test_state():
     tests ran before (or on a test that failed between flipping a switch and restoring it)."""
     import torch
     from medical_image_segmentation_amd import functional as F_
-    names = ("FUSE_BN_SUMS", "BN_SUMS_MIN_NUMEL", "DEFER_WGRAD_REDUCE", "FUSE_HEAD_DZ", "WGRAD_SIDE_STREAM", "FUSE_FAN_OUT", "FUSE_AMSFN_BWD", "CENTER_TAP_CONVS", "BATCH_WEIGHT_PREP", "DEFER_COMPOSED", "FUSE_DGRAD_BN_SUMS", "PROFILE", "DROPOUT_RNG", "call", "query")
+    names = ("FUSE_BN_SUMS", "BN_SUMS_MIN_NUMEL", "DEFER_WGRAD_REDUCE", "FUSE_HEAD_DZ", "WGRAD_SIDE_STREAM", "FUSE_FAN_OUT", "FUSE_AMSFN_BWD", "FUSE_AMSFN_DZ4", "CENTER_TAP_CONVS", "BATCH_WEIGHT_PREP", "DEFER_COMPOSED", "FUSE_DGRAD_BN_SUMS", "PROFILE", "DROPOUT_RNG", "call", "query")
     saved = {n: getattr(F_, n) for n in names if hasattr(F_, n)}
     torch.manual_seed(0)
     try:
