@@ -248,29 +248,55 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
     for (int r = 0; r < 4; r++)
 #pragma unroll
       for (int j = 0; j < CO_T; j++) acc[r][j] = bl[sl][j];
+    // The weights of one tap (CIN x CO_T floats) are read from LDS while the previous tap is multiplied; the
+    // scheduling barrier keeps the compiler from hoisting all 9*CIN*CO_T of them into registers at once (with
+    // three input channels that took 216 registers and spilled 200).
+    f32x4 wq[2][CIN][2];
 #pragma unroll
-    for (int k = 0; k < 9 * CIN; k++) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[sl][k][0]), w1 = *reinterpret_cast<const f32x4*>(&wl[sl][k][4]);
-      const int tap = k / CIN, c = k % CIN;
+    for (int c = 0; c < CIN; c++) {
+      wq[0][c][0] = *reinterpret_cast<const f32x4*>(&wl[sl][c][0]);
+      wq[0][c][1] = *reinterpret_cast<const f32x4*>(&wl[sl][c][4]);
+    }
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float v = xv[c][r + tap / 3][tap % 3];
+    for (int tap = 0; tap < 9; tap++) {
+      if (tap + 1 < 9) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          acc[r][j] += v * w0[j];
-          acc[r][4 + j] += v * w1[j];
+        for (int c = 0; c < CIN; c++) {
+          wq[(tap + 1) & 1][c][0] = *reinterpret_cast<const f32x4*>(&wl[sl][(tap + 1) * CIN + c][0]);
+          wq[(tap + 1) & 1][c][1] = *reinterpret_cast<const f32x4*>(&wl[sl][(tap + 1) * CIN + c][4]);
         }
       }
+#pragma unroll
+      for (int c = 0; c < CIN; c++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float v = xv[c][r + tap / 3][tap % 3];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            acc[r][j] += v * wq[tap & 1][c][0][j];
+            acc[r][4 + j] += v * wq[tap & 1][c][1][j];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // (the sums are complete HERE: without this the compiler sinks each row's multiplications into the branch
+    // that stores the row, and keeps every weight alive until the last of them)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int j = 0; j < CO_T; j++) asm volatile("" : "+v"(acc[r][j]));
     const int gx = x0 + lane;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int gy = y0 + 4 * wv + r;
       if (gy < H && gx < W) {
+        if constexpr (NSL == 1) {
 #pragma unroll
-        for (int j = 0; j < CO_T; j++) {
-          st[j] += acc[r][j];
-          st[CO_T + j] += acc[r][j] * acc[r][j];
+          for (int j = 0; j < CO_T; j++) {
+            st[j] += acc[r][j];
+            st[CO_T + j] += acc[r][j] * acc[r][j];
+          }
         }
         T* zp = z + ((int64_t)(b * H + gy) * W + gx) * Cout + co0;
         if (vec_store) {
