@@ -5,6 +5,7 @@
 //
 // Roofline: HBM for the production uses (first layer: read Cin + write Cout per pixel;
 // 1x1: read Cin + write Cout per pixel).
+#include <type_traits>
 #include "common.h"
 #include "vec.h"
 #include "reduce.h"
@@ -463,7 +464,7 @@ __device__ __forceinline__ float sum_cv(float a) {      // total over the CV adj
 
 // z[p] = bias + sum_{tap, ci} act(x)[p + off(tap)][ci] * w[tap][ci]      (Cin = CV*V -> 1 channel)
 template <typename T, int V, int CV>
-__global__ __launch_bounds__(CD_THREADS) void conv3x3_to1_kernel(const T* __restrict__ x,
+__global__ __launch_bounds__(CD_THREADS, 2) void conv3x3_to1_kernel(const T* __restrict__ x,
                                                                  const T* __restrict__ wp /*[9][1][Cin]*/,
                                                                  const float* __restrict__ bias, T* __restrict__ z,
                                                                  float* __restrict__ partials /*[gridDim.x][2] or null*/,
@@ -485,37 +486,57 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_to1_kernel(const T* __rest
   const float b0 = bias ? bias[0] : 0.f;
   const int strips = (H + NR - 1) / NR, xblocks = (W + PXB - 1) / PXB, items = B * strips * xblocks;
   float st[2] = {0.f, 0.f};
+  // (lazy or plain input decided ONCE: a test per element splits the strip into hundreds of basic blocks)
+  auto run = [&](auto lazy_tag) {
+  constexpr bool LAZY = decltype(lazy_tag)::value;
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int xb = item % xblocks, sy = (item / xblocks) % strips, b = item / (xblocks * strips);
     const int gx = xb * PXB + px, y0 = sy * NR;
     float acc[NR];
 #pragma unroll
     for (int o = 0; o < NR; o++) acc[o] = 0.f;
+    // every load is unconditional (coordinates clamped into the image, the value masked afterwards): no branch
+    // inside the strip, so its 3*(NR+2) loads are in flight together
+    int xc[3];
+    unsigned mx[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int xx = gx + d - 1;
+      mx[d] = (xx >= 0 && xx < W) ? ~0u : 0u;
+      xc[d] = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+    }
+    // (one row of loads ahead of the row being multiplied; the scheduling barrier keeps the compiler from
+    // hoisting all 3*(NR+2) loads and their conversions, which takes every register and one wave per SIMD)
+    float nx[2][3][V];
+    auto load_row = [&](int ri, float (&dst)[3][V]) {
+      const int yy = y0 - 1 + ri, yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
+      for (int d = 0; d < 3; d++) vload<T, V>(x + ((int64_t)(b * H + yc) * W + xc[d]) * Cin + c0, dst[d]);
+    };
+    load_row(0, nx[0]);
 #pragma unroll
     for (int ri = 0; ri < NR + 2; ri++) {
+      if (ri + 1 < NR + 2) load_row(ri + 1, nx[(ri + 1) & 1]);
       const int yy = y0 - 1 + ri;
-      if (yy < 0 || yy >= H) continue;                 // (uniform over the workgroup)
+      const unsigned my = (yy >= 0 && yy < H) ? ~0u : 0u;
 #pragma unroll
-      for (int dx = -1; dx <= 1; dx++) {
-        const int xx = gx + dx;
-        float av[V];
+      for (int d = 0; d < 3; d++) {
+        float (&av)[V] = nx[ri & 1][d];
+        const unsigned m = my & mx[d];
 #pragma unroll
-        for (int k = 0; k < V; k++) av[k] = 0.f;
-        if (xx >= 0 && xx < W) {
-          vload<T, V>(x + ((int64_t)(b * H + yy) * W + xx) * Cin + c0, av);
-          if (in_aff) {
-#pragma unroll
-            for (int k = 0; k < V; k++) av[k] = to_f32(from_f32<T>(fmaxf(av[k] * asc[k] + ash[k], 0.f)));
-          }
+        for (int k = 0; k < V; k++) {
+          if constexpr (LAZY) av[k] = to_f32(from_f32<T>(fmaxf(av[k] * asc[k] + ash[k], 0.f)));
+          av[k] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, av[k]) & m);
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
           const int o = ri - ky;                       // output row that sees this input row through tap row ky
           if (o < 0 || o >= NR) continue;
 #pragma unroll
-          for (int k = 0; k < V; k++) acc[o] += av[k] * wr[ky * 3 + dx + 1][k];
+          for (int k = 0; k < V; k++) acc[o] += av[k] * wr[ky * 3 + d][k];
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int o = 0; o < NR; o++) {
@@ -528,6 +549,8 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_to1_kernel(const T* __rest
       }
     }
   }
+  };
+  if (in_aff) run(std::true_type{}); else run(std::false_type{});
   if (partials) {
     block_sum<2>(st, red);
     if (tid < 2) partials[(int64_t)blockIdx.x * 2 + tid] = tid == 0 ? st[0] : st[1];
@@ -558,20 +581,21 @@ __global__ __launch_bounds__(CD_THREADS, STATS ? 1 : 3) void conv3x3_from1_kerne
     for (int k = 0; k < V; k++) st[0][k] = st[1][k] = 0.f;
   }
   const float asc = in_aff ? in_aff[0] : 1.f, ash = in_aff ? in_aff[1] : 0.f;
+  const bool lazy = in_aff != nullptr;               // (a select per scalar, not a branch: three scalars per output row)
   const int strips = (H + NR - 1) / NR, xblocks = (W + PXB - 1) / PXB, items = B * strips * xblocks;
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int xb = item % xblocks, sy = (item / xblocks) % strips, b = item / (xblocks * strips);
     const int gx = xb * PXB + px, y0 = sy * NR;
-    auto row = [&](int yy, float (&r)[3]) {            // window row yy (padding = 0)
+    auto row = [&](int yy, float (&r)[3]) {            // window row yy (padding = 0); unconditional loads
+      const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
 #pragma unroll
       for (int dx = -1; dx <= 1; dx++) {
-        const int xx = gx + dx;
-        float v = 0.f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-          v = to_f32(x[(int64_t)(b * H + yy) * W + xx]);
-          if (in_aff) v = to_f32(from_f32<T>(fmaxf(v * asc + ash, 0.f)));
-        }
-        r[dx + 1] = v;
+        const int xx = gx + dx, xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        const unsigned m = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? ~0u : 0u;
+        float v = to_f32(x[(int64_t)(b * H + yc) * W + xc]);
+        const float a = to_f32(from_f32<T>(fmaxf(v * asc + ash, 0.f)));
+        v = lazy ? a : v;
+        r[dx + 1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m);
       }
     };
     float xr[3][3];
@@ -640,29 +664,34 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_to1_kernel(const T* 
 #pragma unroll
     for (int k = 0; k < V; k++) acc[t][k] = 0.f;
   const int strips = (H + NR - 1) / NR, xblocks = (W + PXB - 1) / PXB, items = B * strips * xblocks;
+  auto run = [&](auto lazy_tag) {
+  constexpr bool LAZY = decltype(lazy_tag)::value;
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int xb = item % xblocks, sy = (item / xblocks) % strips, b = item / (xblocks * strips);
     const int gx = xb * PXB + px, y0 = sy * NR;
-    if (gx >= W) continue;                             // (no cross-lane work inside the loop)
+    // unconditional loads (clamped coordinates, masked values): the strip is one basic block
     float g[NR + 2][3];                                // gradients around the column (0 outside the image)
 #pragma unroll
     for (int ri = 0; ri < NR + 2; ri++) {
-      const int yy = y0 - 1 + ri;
+      const int yy = y0 - 1 + ri, yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
 #pragma unroll
       for (int dx = -1; dx <= 1; dx++) {
-        const int xx = gx + dx;
-        g[ri][dx + 1] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? to_f32(dz[(int64_t)(b * H + yy) * W + xx]) : 0.f;
+        const int xx = gx + dx, xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        const unsigned m = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? ~0u : 0u;
+        g[ri][dx + 1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, to_f32(dz[(int64_t)(b * H + yc) * W + xc])) & m);
       }
     }
+    const int gxc = gx < W ? gx : W - 1;
 #pragma unroll
     for (int i = 0; i < NR; i++) {
-      const int qy = y0 + i;
-      if (qy >= H) continue;
+      const int qy = y0 + i, qc = qy < H ? qy : H - 1;
+      const unsigned m = (qy < H && gx < W) ? ~0u : 0u;
       float av[V];
-      vload<T, V>(x + ((int64_t)(b * H + qy) * W + gx) * Cin + c0, av);
-      if (x_aff) {
+      vload<T, V>(x + ((int64_t)(b * H + qc) * W + gxc) * Cin + c0, av);
 #pragma unroll
-        for (int k = 0; k < V; k++) av[k] = to_f32(from_f32<T>(fmaxf(av[k] * asc[k] + ash[k], 0.f)));
+      for (int k = 0; k < V; k++) {
+        if constexpr (LAZY) av[k] = to_f32(from_f32<T>(fmaxf(av[k] * asc[k] + ash[k], 0.f)));
+        av[k] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, av[k]) & m);
       }
       // tap (ky, kx) pairs this input pixel with the output pixel (qy - ky + 1, gx - kx + 1)
 #pragma unroll
@@ -673,6 +702,8 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_to1_kernel(const T* 
       }
     }
   }
+  };
+  if (x_aff) run(std::true_type{}); else run(std::false_type{});
   // lanes with the same channel vector: xor butterflies over the pixel bits of the lane index, then the waves
   const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
