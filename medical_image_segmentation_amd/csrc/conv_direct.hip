@@ -12,6 +12,9 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+
 constexpr int CD_THREADS = 256;
 constexpr int CO_T = 8;          // output channels per thread
 constexpr int CI_CHUNK = 32;     // input channels staged in LDS per pass
@@ -244,11 +247,13 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
     for (int sl = 0; sl < NSL; sl++) {
     const int co0 = co_base + sl * CO_T;
     if (NSL > 1 && co0 >= Cout) break;                 // (3 slices run in the 4-slice instantiation)
-    float acc[4][CO_T];
+    // two output channels per multiply-add instruction (v_pk_fma_f32, the input value broadcast to both halves):
+    // the layer is bound by the vector ALU — 9*CIN*CO_T multiply-adds per pixel against 16 stored bytes
+    f32x2 acc2[4][CO_T / 2];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int j = 0; j < CO_T; j++) acc[r][j] = bl[sl][j];
+      for (int j = 0; j < CO_T / 2; j++) acc2[r][j] = f32x2{bl[sl][2 * j], bl[sl][2 * j + 1]};
     // The weights of one tap (CIN x CO_T floats) are read from LDS while the previous tap is multiplied; the
     // scheduling barrier keeps the compiler from hoisting all 9*CIN*CO_T of them into registers at once (with
     // three input channels that took 216 registers and spilled 200).
@@ -272,21 +277,26 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_first_kernel(
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const float v = xv[c][r + tap / 3][tap % 3];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            acc[r][j] += v * wq[tap & 1][c][0][j];
-            acc[r][4 + j] += v * wq[tap & 1][c][1][j];
-          }
+          const f32x2 vv = f32x2{v, v};
+          const f32x4 wa = wq[tap & 1][c][0], wb = wq[tap & 1][c][1];
+          acc2[r][0] = __builtin_elementwise_fma(vv, f32x2{wa[0], wa[1]}, acc2[r][0]);
+          acc2[r][1] = __builtin_elementwise_fma(vv, f32x2{wa[2], wa[3]}, acc2[r][1]);
+          acc2[r][2] = __builtin_elementwise_fma(vv, f32x2{wb[0], wb[1]}, acc2[r][2]);
+          acc2[r][3] = __builtin_elementwise_fma(vv, f32x2{wb[2], wb[3]}, acc2[r][3]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     // (the sums are complete HERE: without this the compiler sinks each row's multiplications into the branch
     // that stores the row, and keeps every weight alive until the last of them)
+    float acc[4][CO_T];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int j = 0; j < CO_T; j++) asm volatile("" : "+v"(acc[r][j]));
+      for (int j = 0; j < CO_T; j++) {
+        acc[r][j] = acc2[r][j / 2][j % 2];
+        asm volatile("" : "+v"(acc[r][j]));
+      }
     const int gx = x0 + lane;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -351,11 +361,11 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
   __shared__ float halo[F_TH + 2][F_TW + 2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int co0 = blockIdx.y * CO_T, ci = blockIdx.z;
-  float acc[9][CO_T];
+  f32x2 acc2[9][CO_T / 2];                 // (two output channels per v_pk_fma_f32: the kernel is bound by the vector ALU)
 #pragma unroll
   for (int t = 0; t < 9; t++)
 #pragma unroll
-    for (int j = 0; j < CO_T; j++) acc[t][j] = 0.f;
+    for (int j = 0; j < CO_T / 2; j++) acc2[t][j] = f32x2{0.f, 0.f};
   const bool vec_dz = (Cout % CO_T == 0) && (sizeof(T) * CO_T == 16) && (((uintptr_t)dz & 15) == 0);
   float asc = 1.f, ash = 0.f;
   if (x_aff) {
@@ -422,15 +432,18 @@ __global__ __launch_bounds__(CD_THREADS) void conv3x3_wgrad_direct_kernel(const 
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int tp = 0; tp < 9; tp++)
+      for (int tp = 0; tp < 9; tp++) {
+        const float v = xv[r + tp / 3][tp % 3];
 #pragma unroll
-        for (int j = 0; j < CO_T; j++) acc[tp][j] += xv[r + tp / 3][tp % 3] * g[r][j];
+        for (int j = 0; j < CO_T / 2; j++)
+          acc2[tp][j] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{g[r][2 * j], g[r][2 * j + 1]}, acc2[tp][j]);
+      }
   }
 #pragma unroll
   for (int t = 0; t < 9; t++)
 #pragma unroll
     for (int j = 0; j < CO_T; j++) {
-      const float s = wave_sum(acc[t][j]);
+      const float s = wave_sum(acc2[t][j / 2][j % 2]);
       if (lane == 0) red[wv * 72 + t * CO_T + j] = s;
     }
   __syncthreads();
