@@ -8,6 +8,7 @@
 // and their backward passes.  The branch outputs arrive as lazy activations (conv output z +
 // BatchNorm affine): every kernel applies relu(z*scale + shift) while loading.  All reductions
 // run in a fixed order (no float atomics).  Every kernel is a streaming pass: HBM-bound.
+#include <type_traits>
 #include "common.h"
 #include "vec.h"
 #include "reduce.h"
@@ -626,25 +627,32 @@ __global__ __launch_bounds__(TPB) void wsum_fwd_kernel(Branches br, const float*
       sh[k][j] = br.aff[k] ? br.aff[k][C + c0 + j] : 0.f;
     }
   const int p1 = (r + 1) * chunk < HW ? (r + 1) * chunk : HW;
+  // (all four branches lazy — the case of the models — is decided once: a test per branch inside the loop puts
+  // each of the four loads into a basic block of its own)
+  auto run = [&](auto all_lazy_tag) {
+    constexpr bool ALL_LAZY = decltype(all_lazy_tag)::value;
 #pragma unroll 2
-  for (int p = r * chunk + pl; p < p1; p += PL) {
-    const int64_t idx = ((int64_t)b * HW + p) * C + c0;
-    float acc[V];
+    for (int p = r * chunk + pl; p < p1; p += PL) {
+      const int64_t idx = ((int64_t)b * HW + p) * C + c0;
+      float a[4][V];
 #pragma unroll
-    for (int j = 0; j < V; j++) acc[j] = 0.f;
+      for (int k = 0; k < 4; k++) vload<T, V>((const T*)br.z[k] + idx, a[k]);
+      float acc[V];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      float a[V];
-      vload<T, V>((const T*)br.z[k] + idx, a);
-      if (br.aff[k]) {
+      for (int j = 0; j < V; j++) acc[j] = 0.f;
 #pragma unroll
-        for (int j = 0; j < V; j++) a[j] = to_f32(from_f32<T>(fmaxf(a[j] * sc[k][j] + sh[k][j], 0.f)));
+      for (int k = 0; k < 4; k++) {
+        if (ALL_LAZY || br.aff[k]) {
+#pragma unroll
+          for (int j = 0; j < V; j++) a[k][j] = to_f32(from_f32<T>(fmaxf(a[k][j] * sc[k][j] + sh[k][j], 0.f)));
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j] += a[k][j] * wk[k][j];
       }
-#pragma unroll
-      for (int j = 0; j < V; j++) acc[j] += a[j] * wk[k][j];
+      vstore<T, V>(out + idx, acc);
     }
-    vstore<T, V>(out + idx, acc);
-  }
+  };
+  if (br.aff[0] && br.aff[1] && br.aff[2] && br.aff[3]) run(std::true_type{}); else run(std::false_type{});
 }
 
 // dact_k[b][p][c] = dout[b][p][c] * w[b][k*C + c] + ds[b][k*C + c] / HW   (weighted sum + average pool)
@@ -732,15 +740,19 @@ __global__ __launch_bounds__(TPB) void branch_stats_kernel(Branches br, BranchBn
         sc[j] = aff ? aff[c0 + j] : 1.f;
         sh[j] = aff ? aff[C + c0 + j] : 0.f;
       }
-#pragma unroll 2
-      for (int p = r * chunk + pl; p < p1; p += PL) {
-        float zv[V];
-        vload<T, V>(zk + ((int64_t)b * HW + p) * C + c0, zv);
-        // the activation as consumers read it (a plain branch tensor has no affine)
+      // the activation as consumers read it (a plain branch tensor has no affine: decided once, not per element)
+      auto run = [&](auto lazy_tag) {
+        constexpr bool LAZY = decltype(lazy_tag)::value;
+#pragma unroll 4
+        for (int p = r * chunk + pl; p < p1; p += PL) {
+          float zv[V];
+          vload<T, V>(zk + ((int64_t)b * HW + p) * C + c0, zv);
 #pragma unroll
-        for (int j = 0; j < V; j++)
-          acc[0][j] += aff ? to_f32(from_f32<T>(fmaxf(zv[j] * sc[j] + sh[j], 0.f))) : zv[j];
-      }
+          for (int j = 0; j < V; j++)
+            acc[0][j] += LAZY ? to_f32(from_f32<T>(fmaxf(zv[j] * sc[j] + sh[j], 0.f))) : zv[j];
+        }
+      };
+      if (aff) run(std::true_type{}); else run(std::false_type{});
     } else {
       float mu[V], rs[V], ga[V], be[V];
 #pragma unroll
