@@ -869,37 +869,54 @@ __global__ __launch_bounds__(CD_THREADS) void conv1x1_bwd_kernel(const T* __rest
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_blk;
   int64_t p1 = p0 + pix_per_blk;
   if (p1 > n_pix) p1 = n_pix;
-  for (int64_t p = p0 + pr; pr < PR && p < p1; p += PR) {
-    float g[CO], xv[V], d[V], zr[V];
-    vload<T, CO>(dy + p * CO, g);
-    vload<T, V>(x + p * Cin + c0, xv);
+  // Lazy / BatchNorm sums are decided once (not per pixel), and UNR pixels are loaded before the first is
+  // multiplied: the loop is otherwise one pixel's two loads deep, with ~150 vector instructions behind them.
+  constexpr int UNR = 4;
+  auto run = [&](auto lazy_tag, auto bn_tag) {
+    constexpr bool LAZY = decltype(lazy_tag)::value, BN = decltype(bn_tag)::value;
+    for (int64_t pb = p0 + pr; pr < PR && pb < p1; pb += (int64_t)UNR * PR) {
+      float g[UNR][CO], xq[UNR][V];
 #pragma unroll
-    for (int k = 0; k < V; k++) zr[k] = xv[k];
-    if (x_aff) {
+      for (int u = 0; u < UNR; u++) {
+        const int64_t p = pb + (int64_t)u * PR, pc = p < p1 ? p : p1 - 1;      // (clamped address; the tail is skipped below)
+        vload<T, CO>(dy + pc * CO, g[u]);
+        vload<T, V>(x + pc * Cin + c0, xq[u]);
+      }
 #pragma unroll
-      for (int k = 0; k < V; k++) xv[k] = fmaxf(xv[k] * asc[k] + ash[k], 0.f);
-    }
+      for (int u = 0; u < UNR; u++) {
+        const int64_t p = pb + (int64_t)u * PR;
+        if (p >= p1) break;
+        float xv[V], d[V], zr[V];
 #pragma unroll
-    for (int k = 0; k < V; k++) d[k] = 0.f;
+        for (int k = 0; k < V; k++) {
+          zr[k] = xq[u][k];
+          xv[k] = LAZY ? fmaxf(zr[k] * asc[k] + ash[k], 0.f) : zr[k];
+          d[k] = 0.f;
+        }
 #pragma unroll
-    for (int j = 0; j < CO; j++) {
-      ab[j] += g[j];
+        for (int j = 0; j < CO; j++) {
+          ab[j] += g[u][j];
 #pragma unroll
-      for (int k = 0; k < V; k++) {
-        d[k] += g[j] * wr[j][k];
-        aw[j][k] += g[j] * xv[k];
+          for (int k = 0; k < V; k++) {
+            d[k] += g[u][j] * wr[j][k];
+            aw[j][k] += g[u][j] * xv[k];
+          }
+        }
+        if (dx) vstore<T, V>(dx + p * Cin + c0, d);
+        if constexpr (BN) {
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            const float dd = (xv[k] > 0.f) ? to_f32(from_f32<T>(d[k])) : 0.f;     // the value the next pass would read
+            bs[0][k] += dd;
+            bs[1][k] += dd * ((zr[k] - bmean[k]) * brstd[k]);
+          }
+        }
       }
     }
-    if (dx) vstore<T, V>(dx + p * Cin + c0, d);
-    if (bn) {
-#pragma unroll
-      for (int k = 0; k < V; k++) {
-        const float dd = (xv[k] > 0.f) ? to_f32(from_f32<T>(d[k])) : 0.f;     // the value the next pass would read
-        bs[0][k] += dd;
-        bs[1][k] += dd * ((zr[k] - bmean[k]) * brstd[k]);
-      }
-    }
-  }
+  };
+  if (bn) run(std::true_type{}, std::true_type{});
+  else if (x_aff) run(std::true_type{}, std::false_type{});
+  else run(std::false_type{}, std::false_type{});
 #pragma unroll
   for (int j = 0; j < CO; j++) {
 #pragma unroll
