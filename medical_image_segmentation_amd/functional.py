@@ -1394,7 +1394,7 @@ class MaxPool3x3Fn(torch.autograd.Function):
         B, Cc, H, W = ctx.dims
         dy = to_act(dy)
         dx = torch.empty_like(dy)
-        with _prof("maxpool3x3_bwd", 0, 2 * dy.numel() * dy.element_size() + 9 * dy.numel()):
+        with _prof("maxpool3x3_bwd", 0, 2 * dy.numel() * dy.element_size() + dy.numel()):
             call("mis_maxpool3x3s1_bwd", dy.data_ptr(), arg.data_ptr(), _dt(dy), B, H, W, Cc, dx.data_ptr(), _stream())
         return dx, None
 
