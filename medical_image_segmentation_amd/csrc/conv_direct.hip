@@ -1048,9 +1048,11 @@ size_t conv3x3_direct_workspace_bytes(int64_t n_pix, int Cout) {
 // Workgroups of the image-facing kernel: two per CU, each with the same whole number of tiles where the
 // tile count allows it (measured at 16 x 512^2: 512 workgroups of 8 tiles 30 us; 1024 x 4: 36; 2048 x 2: 45;
 // 640 uneven: 39) — a longer tile loop amortises the weight staging and keeps the next tile's halo in flight.
-static int first_layer_grid(int B, int H, int W) {
+static int first_layer_grid(int B, int H, int W, int Cin) {
   const int n_tiles = B * cdiv(W, F_TW) * cdiv(H, F_TH);
-  const int per = cdiv(n_tiles, 512);
+  // workgroups resident at once: four per CU with one input channel (112 registers), two with three
+  // (1 -> 8 at 16 x 512^2: 512 workgroups 27.7 us, 1024: 26.0, 2048: 30.7)
+  const int per = cdiv(n_tiles, Cin == 1 ? 1024 : 512);
   return cdiv(n_tiles, per);
 }
 
@@ -1058,7 +1060,7 @@ static int first_layer_grid(int B, int H, int W) {
 // stride, so the count depends on the shape alone (not on which kernel the pointers' alignment allows).
 int conv3x3_direct_stats_rows(int64_t n_pix, int B, int H, int W, int Cin, int Cout) {
   // one input channel into whole channel vectors: the strip kernel wants many short workgroups
-  if ((Cin == 1 || Cin == 3) && !(Cin == 1 && Cout >= 16 && Cout % 4 == 0)) return first_layer_grid(B, H, W);
+  if ((Cin == 1 || Cin == 3) && !(Cin == 1 && Cout >= 16 && Cout % 4 == 0)) return first_layer_grid(B, H, W, Cin);
   int gx = cdiv(n_pix, CD_THREADS);
   return gx > CD_MAX_BLOCKS ? CD_MAX_BLOCKS : gx;
 }
